@@ -1,0 +1,858 @@
+// Engine: host logic around the gfx950 kernels (see engine.hpp).
+#include "engine.hpp"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <fstream>
+#include <set>
+#include <sstream>
+#include <thread>
+
+namespace gfxknn {
+
+using clk = std::chrono::steady_clock;
+
+void hip_check(hipError_t e, const char* what) {
+    if (e == hipSuccess) return;
+    std::string msg = std::string(what) + ": " + hipGetErrorString(e);
+    (void)hipGetLastError();
+    throw EngineError(e == hipErrorOutOfMemory ? Err::OutOfMemory : Err::Runtime, msg);
+}
+
+// ---------------------------------------------------------------------------------------------
+// ParamSet
+// ---------------------------------------------------------------------------------------------
+ParamSet::ParamSet(const std::vector<std::string>& desc) {
+    std::set<std::string> seen;
+    for (const std::string& d : desc) {
+        // AnyParams(const vector<string>&), params.h:50-74: exactly one '=' separating two parts
+        size_t eq = d.find('=');
+        if (eq == std::string::npos || d.find('=', eq + 1) != std::string::npos || eq == 0 || eq + 1 == d.size())
+            throw std::runtime_error("Wrong format of an argument: '" + d + "' should be in the format: <Name>=<Value>");
+        std::string name = d.substr(0, eq), val = d.substr(eq + 1);
+        if (seen.count(name)) throw std::runtime_error("Duplicate parameter: " + name);
+        seen.insert(name);
+        kv_.emplace_back(name, val);
+    }
+    seen_.assign(kv_.size(), false);
+}
+bool ParamSet::has(const std::string& name) const {
+    for (auto& p : kv_)
+        if (p.first == name) return true;
+    return false;
+}
+const std::string* ParamSet::find(const std::string& name) {
+    for (size_t i = 0; i < kv_.size(); ++i)
+        if (kv_[i].first == name) {
+            seen_[i] = true;
+            return &kv_[i].second;
+        }
+    return nullptr;
+}
+template <typename T>
+static void convert(const std::string& s, T& v) {
+    std::stringstream str(s);
+    if (!(str >> v) || !str.eof()) throw std::runtime_error("Failed to convert value '" + s + "'");
+}
+void ParamSet::get(const std::string& name, long long& v) {
+    if (auto s = find(name)) convert(*s, v);
+}
+void ParamSet::get(const std::string& name, int& v) {
+    if (auto s = find(name)) convert(*s, v);
+}
+void ParamSet::get(const std::string& name, size_t& v) {
+    if (auto s = find(name)) convert(*s, v);
+}
+void ParamSet::get(const std::string& name, double& v) {
+    if (auto s = find(name)) convert(*s, v);
+}
+void ParamSet::get(const std::string& name, bool& v) {
+    if (auto s = find(name)) convert(*s, v);
+}
+void ParamSet::get(const std::string& name, std::string& v) {
+    if (auto s = find(name)) v = *s;
+}
+void ParamSet::check_unused() const {
+    for (size_t i = 0; i < kv_.size(); ++i)
+        if (!seen_[i]) throw std::runtime_error("Unknown parameters found!");
+}
+
+// ---------------------------------------------------------------------------------------------
+// DevBuf
+// ---------------------------------------------------------------------------------------------
+void* DevBuf::ensure(size_t bytes) {
+    if (bytes <= n_ && p_) return p_;
+    release();
+    if (bytes == 0) bytes = 16;
+    hip_check(hipMalloc(&p_, bytes), "hipMalloc");
+    n_ = bytes;
+    return p_;
+}
+void DevBuf::release() {
+    if (p_) (void)hipFree(p_);
+    p_ = nullptr;
+    n_ = 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Engine: construction / data
+// ---------------------------------------------------------------------------------------------
+static int space_from_name(const std::string& s) {
+    // registered dense names: include/factory/init_spaces.h:77-86,120
+    if (s == "l2") return SP_L2;
+    if (s == "l1") return SP_L1;
+    if (s == "linf") return SP_LINF;
+    if (s == "cosinesimil") return SP_COSINE;
+    if (s == "angulardist") return SP_ANGULAR;
+    if (s == "negdotprod") return SP_NEGDOT;
+    if (s == "l2sqr_sift") return SP_L2SQR_SIFT;
+    return -1;
+}
+
+Engine::Engine(const std::string& space, const std::string& method, int data_type, int dist_type)
+    : space_name_(space), method_name_(method) {
+    (void)dist_type;
+    const int sp = space_from_name(space);
+    if (sp < 0)
+        throw EngineError(Err::SpaceIncompatible,
+                          "space '" + space + "' is not served by the GPU engine (dense spaces: l2, l1, linf, "
+                          "cosinesimil, angulardist, negdotprod, l2sqr_sift)");
+    space_ = sp;
+    // data_type: 0 dense float, 2 dense uint8 (nmslib_c.h:12-17)
+    if (data_type != 0 && data_type != 2)
+        throw EngineError(Err::SpaceIncompatible, "only dense float and dense uint8 data are served by the GPU engine");
+    if ((sp == SP_L2SQR_SIFT) != (data_type == 2))
+        throw EngineError(Err::SpaceIncompatible, "data type does not match space '" + space + "'");
+    // The method name is resolved at nmslib_create_index, like the reference
+    // (MethodFactoryRegistry::CreateMethod, nmslib_c.cpp:493-496).
+    thread_pool_size = std::thread::hardware_concurrency();
+}
+
+Engine::~Engine() {
+    if (stream_) (void)hipStreamDestroy(stream_);
+}
+
+void Engine::add_row(const void* data, size_t elem_count, int32_t id) {
+    if (is_u8()) {
+        // CreateObjFromUint8Vect CHECKs size == SIFT_DIM (space_l2sqr_sift.cc:136-140)
+        if (elem_count != 128) throw EngineError(Err::Runtime, "SIFT vectors must have 128 bytes");
+        if (dim_ == 0) dim_ = 128;
+        const uint8_t* p = static_cast<const uint8_t*>(data);
+        rows_u8_.insert(rows_u8_.end(), p, p + 128);
+    } else {
+        if (dim_ == 0) dim_ = elem_count;
+        if (elem_count != dim_)
+            throw EngineError(Err::InvalidArgument, "all rows of a dense index must have the same dimension");
+        const float* p = static_cast<const float*>(data);
+        rows_f32_.insert(rows_f32_.end(), p, p + elem_count);
+    }
+    ids_.push_back(id);
+    dirty_ = true;
+    graph_dirty_ = true;
+}
+
+const void* Engine::host_row(size_t pos) const {
+    return is_u8() ? static_cast<const void*>(&rows_u8_[pos * 128]) : static_cast<const void*>(&rows_f32_[pos * dim_]);
+}
+
+void Engine::stored_row(size_t pos, void* dst) const {
+    if (is_u8()) {
+        // payload = 128 bytes + int32 sum of squares (space_l2sqr_sift.cc:146-149)
+        std::memcpy(dst, &rows_u8_[pos * 128], 128);
+        int32_t s = 0;
+        for (int i = 0; i < 128; ++i) s += (int32_t)rows_u8_[pos * 128 + i] * (int32_t)rows_u8_[pos * 128 + i];
+        std::memcpy(static_cast<char*>(dst) + 128, &s, 4);
+    } else {
+        std::memcpy(dst, &rows_f32_[pos * dim_], dim_ * 4);
+    }
+}
+
+void Engine::reset() {
+    ids_.clear();
+    rows_f32_.clear();
+    rows_u8_.clear();
+    graph_ = HostGraph();
+    graph_rows_.clear();
+    loaded_graph_ = false;
+    created_ = false;
+    dirty_ = true;
+    graph_dirty_ = true;
+    d_n_ = 0;
+}
+
+size_t Engine::memory_usage() const {
+    // nmslib_index_memory_usage (nmslib_c.cpp:1546-1565): object buffers + n*dim*4
+    if (!created_) return 0;
+    size_t total = ids_.size() * (16 + stored_row_bytes());
+    total += ids_.size() * dim_ * sizeof(float);
+    return total;
+}
+
+size_t Engine::hbm_bytes() const {
+    return d_rows_.bytes() + d_aux_.bytes() + d_ids_.bytes() + d_links0_.bytes() + d_up_off_.bytes() +
+           d_up_links_.bytes() + d_rownorm_.bytes();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Index / query parameters
+// ---------------------------------------------------------------------------------------------
+void Engine::create_index(const std::vector<std::string>& params) {
+    ParamSet ps(params);
+    int defer = 0;
+    if (method_name_ == "hnsw") {
+        method_ = Method::Hnsw;
+        HnswBuildParams bp;
+        // Hnsw::CreateIndex, hnsw.cc:187-208
+        ps.get("M", bp.M);
+        int search_method = 0;
+        ps.get("searchMethod", search_method);
+        ps.get("indexThreadQty", bp.threads);
+        ps.get("efConstruction", bp.efConstruction);
+        bp.maxM = bp.M;
+        ps.get("maxM", bp.maxM);
+        bp.maxM0 = bp.M * 2;
+        ps.get("maxM0", bp.maxM0);
+        ps.get("mult", bp.mult);
+        ps.get("delaunay_type", bp.delaunay);
+        ps.get("post", bp.post);
+        int skip = 0;
+        ps.get("skip_optimized_index", skip);
+        bp.skip_optimized = skip != 0;
+        ps.get("gpu_defer", defer);  // engine extension: build now, upload to HBM at first use
+        ps.check_unused();
+        bp_ = bp;
+        ef_ = 200;  // the shim forces efSearch=200 per query (nmslib_c.cpp:330,986)
+        algo_ = "hybrid";
+    } else if (method_name_ == "brute_force" || method_name_ == "seq_search") {
+        method_ = Method::Brute;
+        bool copy_mem = false, multi = false;
+        size_t thread_qty = 0;
+        ps.get("copyMem", copy_mem);  // SeqSearch::CreateIndex, seqsearch.cc:63-66
+        ps.get("multiThread", multi);
+        ps.get("threadQty", thread_qty);
+        ps.get("gpu_defer", defer);
+        ps.check_unused();
+    } else {
+        throw EngineError(Err::IndexBuildFailed,
+                          "method '" + method_name_ + "' is not served by the GPU engine (hnsw, brute_force, seq_search)");
+    }
+    created_ = true;
+    dirty_ = true;
+    graph_dirty_ = true;
+    loaded_graph_ = false;
+    if (!ids_.empty()) {
+        if (defer) ensure_graph();
+        else finalize();
+    }
+}
+
+void Engine::set_query_params(const std::vector<std::string>& params) {
+    ParamSet ps(params);
+    if (method_ == Method::Hnsw) {
+        // Hnsw::SetQueryTimeParams, hnsw.cc:472-507
+        if (ps.has("ef") && ps.has("efSearch"))
+            throw std::runtime_error("The user shouldn't specify parameters ef and efSearch at the same time");
+        size_t ef = 20;
+        ps.get("ef", ef);
+        ps.get("efSearch", ef);
+        int tmp = 0;
+        ps.get("searchMethod", tmp);
+        std::string algo = "hybrid";
+        ps.get("algoType", algo);
+        std::transform(algo.begin(), algo.end(), algo.begin(), ::tolower);
+        if (algo != "v1merge" && algo != "old" && algo != "hybrid")
+            throw std::runtime_error("algoType should be one of the following: old, v1merge");
+        ps.check_unused();
+        if (ef < 1) throw std::runtime_error("ef must be positive");
+        ef_ = (int)ef;
+        algo_ = algo;
+    } else {
+        ps.check_unused();  // SeqSearch has no query-time parameters
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Device residency
+// ---------------------------------------------------------------------------------------------
+void Engine::check_device() {
+    if (device_ >= 0) {
+        hip_check(hipSetDevice(device_), "hipSetDevice");
+        return;
+    }
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count == 0) {
+        (void)hipGetLastError();
+        throw EngineError(Err::Runtime,
+                          "no HIP device available: the k-NN path of this library runs only on the GPU "
+                          "(there is no CPU fallback)");
+    }
+    int dev = 0;
+    if (const char* env = getenv("NMSLIB_GPU_DEVICE")) dev = atoi(env);
+    else if (const char* lr = getenv("LOCAL_RANK")) dev = atoi(lr) % count;
+    hip_check(hipSetDevice(dev), "hipSetDevice");
+    device_ = dev;
+    hip_check(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking), "hipStreamCreate");
+}
+
+void Engine::upload_rows() {
+    const size_t n = ids_.size();
+    auto t0 = clk::now();
+    if (is_u8()) {
+        ldb_ = 128;
+        d_rows_.ensure(std::max<size_t>(n, 1) * 128);
+        if (n) hip_check(hipMemcpy(d_rows_.ptr(), rows_u8_.data(), n * 128, hipMemcpyHostToDevice), "upload rows");
+    } else {
+        ldb_ = f32_row_stride((int)dim_);
+        d_rows_.ensure(std::max<size_t>(n, 1) * ldb_ * 4);
+        const float* src = rows_f32_.data();
+        if (loaded_graph_ && !graph_rows_.empty()) src = graph_rows_.data();
+        if (n) {
+            hip_check(hipMemset(d_rows_.ptr(), 0, n * ldb_ * 4), "clear rows");
+            hip_check(hipMemcpy2D(d_rows_.ptr(), (size_t)ldb_ * 4, src, dim_ * 4, dim_ * 4, n, hipMemcpyHostToDevice),
+                      "upload rows");
+        }
+    }
+    d_ids_.ensure(std::max<size_t>(n, 1) * 4);
+    if (n) hip_check(hipMemcpy(d_ids_.ptr(), ids_.data(), n * 4, hipMemcpyHostToDevice), "upload ids");
+    d_n_ = n;
+    upload_seconds = std::chrono::duration<double>(clk::now() - t0).count();
+}
+
+void Engine::build_graph() {
+    auto t0 = clk::now();
+    if (!loaded_graph_) {
+        const void* rows = is_u8() ? static_cast<const void*>(rows_u8_.data()) : static_cast<const void*>(rows_f32_.data());
+        hnsw_build_host(space_, rows, ids_.size(), dim_, bp_, graph_);
+    }
+    build_seconds = std::chrono::duration<double>(clk::now() - t0).count();
+}
+
+void Engine::upload_graph() {
+    const HostGraph& g = graph_;
+    const size_t n = (size_t)g.n;
+    d_links0_.ensure(std::max<size_t>(g.links0.size(), 1) * 4);
+    d_up_off_.ensure(std::max<size_t>(n, 1) * 8);
+    d_up_links_.ensure(std::max<size_t>(g.up_links.size(), 1) * 4);
+    if (n) {
+        hip_check(hipMemcpy(d_links0_.ptr(), g.links0.data(), g.links0.size() * 4, hipMemcpyHostToDevice), "links0");
+        hip_check(hipMemcpy(d_up_off_.ptr(), g.up_off.data(), n * 8, hipMemcpyHostToDevice), "up_off");
+        if (!g.up_links.empty())
+            hip_check(hipMemcpy(d_up_links_.ptr(), g.up_links.data(), g.up_links.size() * 4, hipMemcpyHostToDevice),
+                      "up_links");
+    }
+    // search-time distance of the flat ("optimized") index, hnsw.cc:369-412
+    int sspace = space_;
+    bool normalize = false;
+    const bool optimized = !bp_.skip_optimized;
+    if (optimized) {
+        if (space_ == SP_L2) sspace = SP_L2SQR;
+        else if (space_ == SP_COSINE) {
+            sspace = SP_NORMCOS;
+            normalize = true;
+        }
+    }
+    if (normalize && !(loaded_graph_ && !graph_rows_.empty()))
+        hip_check(launch_normalize_rows(d_rows_.as<float>(), (int)n, ldb_, (int)dim_, stream_), "normalize rows");
+    if (is_u8()) {
+        d_rownorm_.ensure(std::max<size_t>(n, 1) * 4);
+        std::vector<int32_t> norms(n);
+        for (size_t i = 0; i < n; ++i) {
+            int32_t s = 0;
+            for (int t = 0; t < 128; ++t) s += (int32_t)rows_u8_[i * 128 + t] * (int32_t)rows_u8_[i * 128 + t];
+            norms[i] = s;
+        }
+        if (n) hip_check(hipMemcpy(d_rownorm_.ptr(), norms.data(), n * 4, hipMemcpyHostToDevice), "row norms");
+    }
+    dg_ = HnswDeviceGraph{};
+    dg_.rows = d_rows_.ptr();
+    dg_.row_norm = d_rownorm_.as<int32_t>();
+    dg_.links0 = d_links0_.as<int32_t>();
+    dg_.up_off = d_up_off_.as<int64_t>();
+    dg_.up_links = d_up_links_.as<int32_t>();
+    dg_.ext_ids = d_ids_.as<int32_t>();
+    dg_.n = (int)n;
+    dg_.dim = (int)dim_;
+    dg_.ldv = is_u8() ? 128 : ldb_;
+    dg_.maxM = g.maxM;
+    dg_.maxM0 = g.maxM0;
+    dg_.maxlevel = g.maxlevel;
+    dg_.enterpoint = g.enterpoint;
+    dg_.space = sspace;
+    dg_.normalize_query = normalize ? 1 : 0;
+    hip_check(hipStreamSynchronize(stream_), "graph upload");
+}
+
+void Engine::ensure_graph() {
+    if (method_ != Method::Hnsw || !graph_dirty_) return;
+    build_graph();
+    graph_dirty_ = false;
+}
+
+void Engine::finalize() {
+    if (!created_) throw EngineError(Err::IndexBuildFailed, "Index not built");
+    if (!dirty_) return;
+    ensure_graph();  // host-side construction first: it needs no device
+    check_device();
+    upload_rows();
+    if (method_ == Method::Brute) {
+        const size_t n = ids_.size();
+        if (is_u8()) {
+            d_aux_.ensure(std::max<size_t>(n, 1) * 4);
+            hip_check(launch_row_aux_u8(d_rows_.as<uint8_t>(), (int)n, d_aux_.as<int32_t>(), stream_), "row aux");
+        } else {
+            d_aux_.ensure(std::max<size_t>(n, 1) * 4);
+            hip_check(launch_row_aux_f32(d_rows_.as<float>(), (int)n, ldb_, (int)dim_, space_, d_aux_.as<float>(), stream_),
+                      "row aux");
+        }
+        hip_check(hipStreamSynchronize(stream_), "finalize");
+    } else {
+        upload_graph();
+    }
+    dirty_ = false;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Queries
+// ---------------------------------------------------------------------------------------------
+void Engine::knn_device(const void* d_queries, size_t nq, size_t elem_count, size_t k, int32_t* d_ids,
+                        float* d_dists, int32_t* d_cnt, hipStream_t stream) {
+    if (!created_) throw EngineError(Err::IndexBuildFailed, "Index not built");
+    if (dirty_) finalize();
+    check_device();
+    if (nq == 0) return;
+    if (k == 0) throw EngineError(Err::InvalidArgument, "k must be positive");
+    if (d_n_ > 0 && elem_count != dim_)
+        // SpaceLp::HiddenDistance CHECKs equal lengths (space_lp.cc:27-35) -> the query fails
+        throw EngineError(Err::QueryExecutionFailed, "query dimension does not match the index");
+    if (method_ == Method::Brute) knn_brute(d_queries, nq, k, d_ids, d_dists, d_cnt, stream);
+    else knn_hnsw(d_queries, nq, k, d_ids, d_dists, d_cnt, stream);
+}
+
+void Engine::knn_brute(const void* d_queries, size_t nq, size_t k, int32_t* d_ids, float* d_dists, int32_t* d_cnt,
+                       hipStream_t stream) {
+    have_counters_ = false;
+    if (k > (size_t)BF_MAX_K)
+        throw EngineError(Err::QueryTooLarge, "k larger than " + std::to_string(BF_MAX_K) +
+                                                  " is not supported by the brute-force GPU kernels");
+    const int dim_eff = d_n_ ? (int)dim_ : 1;
+    BfPlan p = bf_make_plan((int)d_n_, dim_eff, (int)nq, (int)k, is_u8());
+    if (d_n_ == 0) p.ldb = is_u8() ? 128 : f32_row_stride(dim_eff);
+    const int elem = is_u8() ? 1 : 4;
+    ws_qpad_.ensure((size_t)p.qpad * p.ldb * elem);
+    ws_cand_.ensure(bf_cand_elems(p) * 8);
+    ws_cnt_.ensure(bf_cnt_elems(p) * 4);
+    hip_check(launch_pad_rows(d_queries, (int)nq, dim_eff, ws_qpad_.ptr(), p.qpad, p.ldb, elem, stream), "pad queries");
+    if (is_u8()) {
+        hip_check(launch_bf_select_u8(p, d_rows_.as<uint8_t>(), d_aux_.as<int32_t>(), ws_qpad_.as<uint8_t>(),
+                                      ws_cand_.as<unsigned long long>(), ws_cnt_.as<int>(), stream),
+                  "bf_select_u8");
+    } else if (space_ == SP_L1 || space_ == SP_LINF) {
+        hip_check(launch_bf_select_direct_f32(p, space_, d_rows_.as<float>(), ws_qpad_.as<float>(),
+                                              ws_cand_.as<unsigned long long>(), ws_cnt_.as<int>(), stream),
+                  "bf_select_direct");
+    } else {
+        hip_check(launch_bf_select_f32(p, space_, d_rows_.as<float>(), d_aux_.as<float>(), ws_qpad_.as<float>(),
+                                       ws_cand_.as<unsigned long long>(), ws_cnt_.as<int>(), stream),
+                  "bf_select_f32");
+    }
+    hip_check(launch_bf_rerank(p, space_, dim_eff, (int)k, d_rows_.ptr(), ws_qpad_.ptr(),
+                               ws_cand_.as<unsigned long long>(), ws_cnt_.as<int>(), d_ids_.as<int32_t>(), d_ids,
+                               d_dists, d_cnt, stream),
+              "bf_rerank");
+}
+
+void Engine::knn_hnsw(const void* d_queries, size_t nq, size_t k, int32_t* d_ids, float* d_dists, int32_t* d_cnt,
+                      hipStream_t stream) {
+    const int ef = ef_;
+    if (std::max<size_t>(ef, k) > 1024)
+        throw EngineError(Err::QueryTooLarge, "max(ef, k) larger than 1024 is not supported by the HNSW GPU kernel");
+    ws_ndc_.ensure(nq * 4);
+    ws_hops_.ensure(nq * 4);
+    ws_hops_up_.ensure(nq * 4);
+    ws_status_.ensure(nq * 4);
+    DevBuf tmp_cnt;
+    int32_t* cnt = d_cnt;
+    if (!cnt) {
+        ws_outcnt_.ensure(nq * 4);
+        cnt = ws_outcnt_.as<int32_t>();
+    }
+    HnswSearchPlan p = hnsw_make_plan(dg_, (int)nq, (int)k, ef, false);
+    uint32_t* bitset = nullptr;
+    if (p.table_size == 0) {
+        ws_bitset_.ensure(nq * p.bitset_words * 4);
+        hip_check(hipMemsetAsync(ws_bitset_.ptr(), 0, nq * p.bitset_words * 4, stream), "clear visited bitset");
+        bitset = ws_bitset_.as<uint32_t>();
+    }
+    hip_check(launch_hnsw_search(dg_, p, d_queries, bitset, d_ids, d_dists, cnt, ws_ndc_.as<int32_t>(),
+                                 ws_hops_.as<int32_t>(), ws_hops_up_.as<int32_t>(), ws_status_.as<int32_t>(), stream),
+              "hnsw_search");
+    have_counters_ = true;
+    if (p.table_size != 0) {
+        // the LDS visited table is exact but finite: queries that filled it report status 1
+        // and are re-run with the HBM bitset variant (rare; costs one host sync)
+        std::vector<int32_t> status(nq);
+        hip_check(hipMemcpyAsync(status.data(), ws_status_.ptr(), nq * 4, hipMemcpyDeviceToHost, stream), "status");
+        hip_check(hipStreamSynchronize(stream), "hnsw_search");
+        bool any = false;
+        for (int32_t s : status) any |= (s != 0);
+        if (any) {
+            HnswSearchPlan pb = hnsw_make_plan(dg_, (int)nq, (int)k, ef, true);
+            ws_bitset_.ensure(nq * pb.bitset_words * 4);
+            hip_check(hipMemsetAsync(ws_bitset_.ptr(), 0, nq * pb.bitset_words * 4, stream), "clear visited bitset");
+            hip_check(launch_hnsw_search(dg_, pb, d_queries, ws_bitset_.as<uint32_t>(), d_ids, d_dists, cnt,
+                                         ws_ndc_.as<int32_t>(), ws_hops_.as<int32_t>(), ws_hops_up_.as<int32_t>(),
+                                         ws_status_.as<int32_t>(), stream),
+                      "hnsw_search(bitset)");
+        }
+    }
+}
+
+void Engine::knn_host(const void* queries, size_t nq, size_t elem_count, size_t k, std::vector<int32_t>& ids,
+                      std::vector<float>& dists, std::vector<int32_t>& cnt) {
+    if (!created_) throw EngineError(Err::IndexBuildFailed, "Index not built");
+    if (dirty_) finalize();
+    check_device();
+    const size_t qbytes = nq * elem_count * elem_bytes();
+    ws_q_.ensure(qbytes);
+    ws_ids_.ensure(nq * k * 4);
+    ws_dists_.ensure(nq * k * 4);
+    ws_outcnt_.ensure(nq * 4);
+    hip_check(hipMemcpyAsync(ws_q_.ptr(), queries, qbytes, hipMemcpyHostToDevice, stream_), "queries H2D");
+    knn_device(ws_q_.ptr(), nq, elem_count, k, ws_ids_.as<int32_t>(), ws_dists_.as<float>(), ws_outcnt_.as<int32_t>(),
+               stream_);
+    ids.resize(nq * k);
+    dists.resize(nq * k);
+    cnt.resize(nq);
+    hip_check(hipMemcpyAsync(ids.data(), ws_ids_.ptr(), nq * k * 4, hipMemcpyDeviceToHost, stream_), "ids D2H");
+    hip_check(hipMemcpyAsync(dists.data(), ws_dists_.ptr(), nq * k * 4, hipMemcpyDeviceToHost, stream_), "dists D2H");
+    hip_check(hipMemcpyAsync(cnt.data(), ws_outcnt_.ptr(), nq * 4, hipMemcpyDeviceToHost, stream_), "cnt D2H");
+    hip_check(hipStreamSynchronize(stream_), "knn");
+}
+
+float Engine::pair_distance(size_t p1, size_t p2) {
+    // Space::IndexTimeDistance on the ORIGINAL rows (nmslib_c.cpp:1166), one wave on the GPU
+    check_device();
+    const size_t rb = is_u8() ? 128 : (size_t)f32_row_stride((int)dim_) * 4;
+    ws_pair_.ensure(2 * rb + 16);
+    hip_check(hipMemsetAsync(ws_pair_.ptr(), 0, 2 * rb + 16, stream_), "pair clear");
+    char* base = ws_pair_.as<char>();
+    hip_check(hipMemcpyAsync(base, host_row(p1), row_bytes(), hipMemcpyHostToDevice, stream_), "pair H2D");
+    hip_check(hipMemcpyAsync(base + rb, host_row(p2), row_bytes(), hipMemcpyHostToDevice, stream_), "pair H2D");
+    float* out = reinterpret_cast<float*>(base + 2 * rb);
+    hip_check(launch_pair_distance(space_, base, base + rb, (int)dim_, out, stream_), "pair_distance");
+    float v = 0;
+    hip_check(hipMemcpyAsync(&v, out, 4, hipMemcpyDeviceToHost, stream_), "pair D2H");
+    hip_check(hipStreamSynchronize(stream_), "pair_distance");
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Persistence: the reference's own formats
+//   <path>      optimized HNSW index, hnsw.cc:774-806 / 1025-1074
+//   <path>.dat  object vector, space.cc:88-105
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+static void wr(std::ostream& o, const T& v) {
+    o.write(reinterpret_cast<const char*>(&v), sizeof(T));
+}
+template <typename T>
+static void rd(std::istream& i, T& v) {
+    i.read(reinterpret_cast<char*>(&v), sizeof(T));
+    if (!i) throw EngineError(Err::DataIO, "unexpected end of index file");
+}
+
+void Engine::save(const std::string& path, bool save_data) {
+    if (!created_) throw EngineError(Err::InvalidArgument, "Index not built");
+    ensure_graph();  // persistence is host-side: no device needed
+    const size_t n = ids_.size();
+    if (save_data) {
+        std::ofstream out(path + ".dat", std::ios::binary);
+        if (!out) throw EngineError(Err::DataIO, "Cannot open file '" + path + ".dat' for writing");
+        wr(out, (uint64_t)n);
+        std::vector<char> buf(16 + stored_row_bytes());
+        for (size_t i = 0; i < n; ++i) {
+            const uint64_t len = 16 + stored_row_bytes();
+            wr(out, len);
+            const int32_t id = ids_[i], label = -1;
+            const uint64_t dl = stored_row_bytes();
+            std::memcpy(&buf[0], &id, 4);
+            std::memcpy(&buf[4], &label, 4);
+            std::memcpy(&buf[8], &dl, 8);
+            stored_row(i, &buf[16]);
+            out.write(buf.data(), (std::streamsize)buf.size());
+        }
+        if (!out) throw EngineError(Err::DataIO, "write failed: " + path + ".dat");
+    }
+    if (method_ != Method::Hnsw)
+        // Index::SaveIndex default throws for SeqSearch (include/index.h:56-58)
+        throw EngineError(Err::DataIO, "SaveIndex is not implemented for method: Sequential search");
+    int dist_func = -1;
+    if (!bp_.skip_optimized) {
+        if (space_ == SP_L2) dist_func = (dim_ % 16 == 0) ? 1 : 2;
+        else if (space_ == SP_COSINE) dist_func = 3;
+        else if (space_ == SP_NEGDOT) dist_func = 4;
+        else if (space_ == SP_L1) dist_func = 5;
+        else if (space_ == SP_LINF) dist_func = 6;
+    }
+    std::ofstream out(path, std::ios::binary);
+    if (!out) throw EngineError(Err::DataIO, "Cannot open file '" + path + "' for writing");
+    const HostGraph& g = graph_;
+    if (dist_func < 0) {
+        // regular (non-optimized) index, SaveRegularIndexBin hnsw.cc:808-840
+        wr(out, (uint32_t)0);
+        wr(out, (uint32_t)n);
+        wr(out, (int32_t)g.maxlevel);
+        wr(out, (uint32_t)g.enterpoint);
+        wr(out, (uint64_t)g.M);
+        wr(out, (uint64_t)g.maxM);
+        wr(out, (uint64_t)g.maxM0);
+        for (size_t i = 0; i < n; ++i) {
+            wr(out, (uint32_t)g.levels[i]);
+            for (int l = 0; l <= g.levels[i]; ++l) {
+                const int32_t* L = l == 0 ? &g.links0[i * (g.maxM0 + 1)]
+                                          : &g.up_links[g.up_off[i] + (size_t)(l - 1) * (g.maxM + 1)];
+                wr(out, (uint32_t)L[0]);
+                out.write(reinterpret_cast<const char*>(L + 1), (std::streamsize)L[0] * 4);
+            }
+        }
+    } else {
+        const uint64_t data_section = 16 + dim_ * 4;
+        const uint64_t mem_per_obj = data_section + (uint64_t)(g.maxM0 + 1) * 4;
+        wr(out, (uint32_t)1);
+        wr(out, (uint32_t)n);
+        wr(out, mem_per_obj);
+        wr(out, data_section);   // offsetLevel0_
+        wr(out, (uint64_t)0);    // offsetData_
+        wr(out, (int32_t)g.maxlevel);
+        wr(out, (uint32_t)g.enterpoint);
+        wr(out, (uint64_t)g.maxM);
+        wr(out, (uint64_t)g.maxM0);
+        wr(out, (int32_t)dist_func);
+        wr(out, (uint64_t)3);    // searchMethod_
+        std::vector<char> rec(mem_per_obj);
+        std::vector<float> row(dim_);
+        for (size_t i = 0; i < n; ++i) {
+            const int32_t id = ids_[i], label = -1;
+            const uint64_t dl = dim_ * 4;
+            std::memcpy(&rec[0], &id, 4);
+            std::memcpy(&rec[4], &label, 4);
+            std::memcpy(&rec[8], &dl, 8);
+            const float* src = (loaded_graph_ && !graph_rows_.empty()) ? &graph_rows_[i * dim_] : &rows_f32_[i * dim_];
+            std::memcpy(row.data(), src, dim_ * 4);
+            if (space_ == SP_COSINE && !(loaded_graph_ && !graph_rows_.empty())) {
+                float s = 0;  // NormalizeVect, hnsw.h:486-497
+                for (size_t d = 0; d < dim_; ++d) s += row[d] * row[d];
+                if (s != 0.0f) {
+                    s = 1 / std::sqrt(s);
+                    for (size_t d = 0; d < dim_; ++d) row[d] *= s;
+                }
+            }
+            std::memcpy(&rec[16], row.data(), dim_ * 4);
+            std::memcpy(&rec[data_section], &g.links0[i * (g.maxM0 + 1)], (size_t)(g.maxM0 + 1) * 4);
+            out.write(rec.data(), (std::streamsize)rec.size());
+        }
+        for (size_t i = 0; i < n; ++i) {
+            const uint32_t bytes = (uint32_t)((size_t)g.levels[i] * (g.maxM + 1) * 4);
+            wr(out, bytes);
+            if (bytes) out.write(reinterpret_cast<const char*>(&g.up_links[g.up_off[i]]), bytes);
+        }
+    }
+    // Trailer (ignored by the reference's readers, which stop after the last node): lets this
+    // library restore the space of an index it saved itself; the reference hard-codes "l2"
+    // on load (nmslib_c.cpp:1421-1429).
+    char trailer[32] = {0};
+    std::memcpy(trailer, "GFXKNNv1", 8);
+    std::strncpy(trailer + 8, space_name_.c_str(), 23);
+    out.write(trailer, 32);
+    if (!out) throw EngineError(Err::DataIO, "write failed: " + path);
+}
+
+std::unique_ptr<Engine> Engine::load(const std::string& path, int data_type, int dist_type, bool load_data) {
+    std::ifstream in(path, std::ios::binary);
+    if (!in) throw EngineError(Err::DataIO, "Cannot open file '" + path + "' for reading");
+    std::string saved_space;
+    {
+        in.seekg(0, std::ios::end);
+        const std::streamoff sz = in.tellg();
+        if (sz >= 36) {
+            char trailer[32];
+            in.seekg(sz - 32);
+            in.read(trailer, 32);
+            if (std::memcmp(trailer, "GFXKNNv1", 8) == 0) {
+                trailer[31] = 0;
+                saved_space = trailer + 8;
+            }
+        }
+        in.clear();
+        in.seekg(0);
+    }
+    uint32_t flag = 0;
+    rd(in, flag);
+    std::unique_ptr<Engine> e;
+    // objects first (.dat), as nmslib_load_index does when load_data is set (nmslib_c.cpp:1430-1434)
+    std::vector<int32_t> dat_ids;
+    std::vector<char> dat_payload;
+    size_t dat_len = 0;
+    if (load_data) {
+        std::ifstream d(path + ".dat", std::ios::binary);
+        if (!d) throw EngineError(Err::DataIO, "Cannot open file '" + path + ".dat' for reading");
+        uint64_t qty = 0;
+        rd(d, qty);
+        for (uint64_t i = 0; i < qty; ++i) {
+            uint64_t osz = 0;
+            rd(d, osz);
+            std::vector<char> buf(osz);
+            d.read(buf.data(), (std::streamsize)osz);
+            if (!d || osz < 16) throw EngineError(Err::DataIO, "corrupt .dat file");
+            int32_t id;
+            uint64_t dl;
+            std::memcpy(&id, &buf[0], 4);
+            std::memcpy(&dl, &buf[8], 8);
+            if (i == 0) dat_len = dl;
+            if (dl != dat_len || dl + 16 != osz) throw EngineError(Err::DataIO, "ragged .dat file");
+            dat_ids.push_back(id);
+            dat_payload.insert(dat_payload.end(), buf.begin() + 16, buf.end());
+        }
+    }
+    if (flag == 1) {
+        uint32_t n;
+        uint64_t mem_per_obj, off_l0, off_data, maxM, maxM0, search_method;
+        int32_t maxlevel, dist_func;
+        uint32_t enterpoint;
+        rd(in, n); rd(in, mem_per_obj); rd(in, off_l0); rd(in, off_data); rd(in, maxlevel); rd(in, enterpoint);
+        rd(in, maxM); rd(in, maxM0); rd(in, dist_func); rd(in, search_method);
+        const char* space = nullptr;
+        switch (dist_func) {  // DistFuncType, hnsw.h:50-58
+            case 1: case 2: space = "l2"; break;
+            case 3: space = "cosinesimil"; break;
+            case 4: space = "negdotprod"; break;
+            case 5: space = "l1"; break;
+            case 6: space = "linf"; break;
+            default: throw EngineError(Err::DataIO, "Unknown distance function code in index file");
+        }
+        if (data_type != 0) throw EngineError(Err::DataIO, "an optimized HNSW index holds dense float vectors");
+        if (off_l0 < off_data + 16 || mem_per_obj < off_l0 + (maxM0 + 1) * 4 || maxM0 > 62 || maxM > 62)
+            throw EngineError(Err::DataIO, "unsupported optimized index geometry");
+        e.reset(new Engine(space, "hnsw", data_type, dist_type));
+        const size_t dim = (off_l0 - off_data - 16) / 4;
+        e->dim_ = dim;
+        HostGraph& g = e->graph_;
+        g.n = (int)n;
+        g.maxM = (int)maxM;
+        g.M = (int)maxM;
+        g.maxM0 = (int)maxM0;
+        g.maxlevel = maxlevel;
+        g.enterpoint = (int)enterpoint;
+        g.levels.assign(n, 0);
+        g.links0.assign((size_t)n * (maxM0 + 1), 0);
+        g.up_off.assign(n, -1);
+        e->graph_rows_.resize((size_t)n * dim);
+        e->ids_.resize(n);
+        std::vector<char> rec(mem_per_obj);
+        for (uint32_t i = 0; i < n; ++i) {
+            in.read(rec.data(), (std::streamsize)mem_per_obj);
+            if (!in) throw EngineError(Err::DataIO, "truncated index file");
+            std::memcpy(&e->ids_[i], &rec[off_data], 4);  // Object header id (object.h:61-77)
+            std::memcpy(&e->graph_rows_[(size_t)i * dim], &rec[off_data + 16], dim * 4);
+            int32_t cnt;
+            std::memcpy(&cnt, &rec[off_l0], 4);
+            if (cnt < 0 || (uint64_t)cnt > maxM0) throw EngineError(Err::DataIO, "corrupt level-0 list");
+            std::memcpy(&g.links0[(size_t)i * (maxM0 + 1)], &rec[off_l0], (size_t)(cnt + 1) * 4);
+        }
+        for (uint32_t i = 0; i < n; ++i) {
+            uint32_t bytes;
+            rd(in, bytes);
+            if (!bytes) continue;
+            const size_t ints = bytes / 4;
+            g.levels[i] = (int)(ints / (maxM + 1));  // the level is not stored: SURVEY.md 8f N1
+            g.up_off[i] = (int64_t)g.up_links.size();
+            const size_t at = g.up_links.size();
+            g.up_links.resize(at + ints);
+            in.read(reinterpret_cast<char*>(&g.up_links[at]), bytes);
+            if (!in) throw EngineError(Err::DataIO, "truncated index file");
+            for (size_t l = 0; l < ints / (maxM + 1); ++l) {  // zero the uninitialised tail slots
+                int32_t* L = &g.up_links[at + l * (maxM + 1)];
+                for (uint64_t j = (uint64_t)L[0] + 1; j <= maxM; ++j) L[j] = 0;
+            }
+        }
+        e->bp_.M = e->bp_.maxM = (int)maxM;
+        e->bp_.maxM0 = (int)maxM0;
+        e->method_ = Method::Hnsw;
+        if (load_data && !dat_ids.empty()) {
+            if (dat_ids.size() != n || dat_len != dim * 4) throw EngineError(Err::DataIO, ".dat does not match the index");
+            e->rows_f32_.resize((size_t)n * dim);
+            std::memcpy(e->rows_f32_.data(), dat_payload.data(), dat_payload.size());
+        } else {
+            e->rows_f32_ = e->graph_rows_;  // rows as stored in the index (cosine: normalised)
+        }
+    } else {
+        // regular index: graph only, rows must come from .dat (LoadRegularIndexBin, hnsw.cc:941-991)
+        if (!load_data || dat_ids.empty()) throw EngineError(Err::DataIO, "a regular HNSW index needs its .dat file");
+        uint32_t n, enterpoint;
+        int32_t maxlevel;
+        uint64_t M, maxM, maxM0;
+        rd(in, n); rd(in, maxlevel); rd(in, enterpoint); rd(in, M); rd(in, maxM); rd(in, maxM0);
+        if (n != dat_ids.size()) throw EngineError(Err::DataIO, "The number of stored elements doesn't match the data");
+        const bool u8 = data_type == 2;
+        // like the reference, a float index without further information is taken to be "l2"
+        e.reset(new Engine(u8 ? "l2sqr_sift" : (saved_space.empty() ? "l2" : saved_space.c_str()), "hnsw", data_type,
+                           dist_type));
+        if (u8) {
+            if (dat_len != 132) throw EngineError(Err::DataIO, "unexpected SIFT payload size");
+            e->dim_ = 128;
+            e->rows_u8_.resize((size_t)n * 128);
+            for (uint32_t i = 0; i < n; ++i) std::memcpy(&e->rows_u8_[(size_t)i * 128], &dat_payload[(size_t)i * 132], 128);
+        } else {
+            e->dim_ = dat_len / 4;
+            e->rows_f32_.resize((size_t)n * e->dim_);
+            std::memcpy(e->rows_f32_.data(), dat_payload.data(), dat_payload.size());
+        }
+        e->ids_ = dat_ids;
+        HostGraph& g = e->graph_;
+        g.n = (int)n;
+        g.M = (int)M;
+        g.maxM = (int)maxM;
+        g.maxM0 = (int)maxM0;
+        g.maxlevel = maxlevel;
+        g.enterpoint = (int)enterpoint;
+        g.levels.assign(n, 0);
+        g.links0.assign((size_t)n * (maxM0 + 1), 0);
+        g.up_off.assign(n, -1);
+        for (uint32_t i = 0; i < n; ++i) {
+            uint32_t lvl;
+            rd(in, lvl);
+            g.levels[i] = (int)lvl;
+            if (lvl) {
+                g.up_off[i] = (int64_t)g.up_links.size();
+                g.up_links.resize(g.up_links.size() + (size_t)lvl * (maxM + 1), 0);
+            }
+            for (uint32_t l = 0; l <= lvl; ++l) {
+                uint32_t qty;
+                rd(in, qty);
+                int32_t* L = l == 0 ? &g.links0[(size_t)i * (maxM0 + 1)]
+                                    : &g.up_links[g.up_off[i] + (size_t)(l - 1) * (maxM + 1)];
+                if (qty > (l == 0 ? maxM0 : maxM)) throw EngineError(Err::DataIO, "corrupt adjacency list");
+                L[0] = (int32_t)qty;
+                in.read(reinterpret_cast<char*>(L + 1), (std::streamsize)qty * 4);
+                if (!in) throw EngineError(Err::DataIO, "truncated index file");
+            }
+        }
+        e->bp_.M = (int)M;
+        e->bp_.maxM = (int)maxM;
+        e->bp_.maxM0 = (int)maxM0;
+        e->bp_.skip_optimized = true;
+        e->method_ = Method::Hnsw;
+        e->graph_rows_.clear();
+    }
+    e->loaded_graph_ = true;
+    e->created_ = true;
+    e->dirty_ = true;
+    e->graph_dirty_ = false;
+    e->ef_ = 200;
+    return e;
+}
+
+}  // namespace gfxknn

@@ -1,0 +1,203 @@
+// Host side of the MI355X k-NN engine: index objects whose rows and graphs live in HBM.
+//
+// Data model (deliberately not NMSLIB's Object* soup, include/object.h:41-104): rows are one
+// row-major array in HBM (stride padded to 32 bytes), external ids a parallel int32 array, the
+// HNSW graph two fixed-stride int32 arrays.  The host keeps a copy of the rows only to serve
+// nmslib_get_data_point / borrow / save and to construct the graph.
+#pragma once
+#include <hip/hip_runtime_api.h>
+
+#include <cstdint>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "kernels/kernels.hpp"
+
+namespace gfxknn {
+
+// ---- errors: thrown inside the engine, mapped to nmslib_error_t at the ABI ----------------
+enum class Err : int {
+    InvalidArgument = 2,
+    OutOfMemory = 3,
+    SpaceIncompatible = 5,
+    QueryTooLarge = 6,
+    IndexBuildFailed = 8,
+    QueryExecutionFailed = 9,
+    DataIO = 10,
+    Runtime = 13,
+};
+struct EngineError : std::runtime_error {
+    Err code;
+    EngineError(Err c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+
+void hip_check(hipError_t e, const char* what);  // throws EngineError(Runtime / OutOfMemory)
+
+// ---- "name=value" parameters (include/params.h:44-74,181-251) -------------------------------
+class ParamSet {
+   public:
+    ParamSet() = default;
+    explicit ParamSet(const std::vector<std::string>& desc);  // throws on bad format / duplicates
+    bool has(const std::string& name) const;
+    // Typed optional getters; conversion failures throw like ConvertStrToValue (params.h:289-299).
+    void get(const std::string& name, long long& v);
+    void get(const std::string& name, int& v);
+    void get(const std::string& name, size_t& v);
+    void get(const std::string& name, double& v);
+    void get(const std::string& name, bool& v);
+    void get(const std::string& name, std::string& v);
+    void check_unused() const;  // AnyParamManager::CheckUnused (params.h:241-251)
+
+   private:
+    const std::string* find(const std::string& name);
+    std::vector<std::pair<std::string, std::string>> kv_;
+    std::vector<bool> seen_;
+};
+
+// ---- device buffer ---------------------------------------------------------------------------
+class DevBuf {
+   public:
+    DevBuf() = default;
+    ~DevBuf() { release(); }
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    void* ensure(size_t bytes);  // grow-only
+    void release();
+    void* ptr() const { return p_; }
+    template <typename T>
+    T* as() const {
+        return static_cast<T*>(p_);
+    }
+    size_t bytes() const { return n_; }
+
+   private:
+    void* p_ = nullptr;
+    size_t n_ = 0;
+};
+
+// ---- HNSW graph on the host (flat arrays; same layout goes to HBM) ---------------------------
+struct HostGraph {
+    int n = 0, M = 16, maxM = 16, maxM0 = 32, efConstruction = 200, delaunay = 2;
+    int maxlevel = 0, enterpoint = 0;
+    std::vector<int32_t> levels;    // [n]
+    std::vector<int32_t> links0;    // [n][maxM0+1] = count, ids...
+    std::vector<int64_t> up_off;    // [n] offset (ints) into up_links, -1 if level 0 only
+    std::vector<int32_t> up_links;  // per node: level blocks of (maxM+1) ints
+    bool empty() const { return n == 0; }
+};
+
+struct HnswBuildParams {
+    int M = 16, maxM = 16, maxM0 = 32, efConstruction = 200, delaunay = 2, post = 0;
+    int threads = 0;  // 0 = hardware concurrency
+    double mult = 0;  // 0 = 1/ln(M)
+    bool skip_optimized = false;
+};
+
+// Construct the graph (restates Hnsw::add / kSearchElementsWithAttemptsLevel /
+// getNeighborsByHeuristic2 / addFriendlevel, src/method/hnsw.cc:534-708, include/method/hnsw.h:
+// 129-169,258-314) with `threads` workers.  space = index-time SpaceCode.  rows: f32 [n][dim]
+// or u8 [n][128].
+void hnsw_build_host(int space, const void* rows, size_t n, size_t dim, const HnswBuildParams& bp,
+                     HostGraph& out);
+
+// ---- the index ---------------------------------------------------------------------------------
+enum class Method { Brute, Hnsw };
+
+class Engine {
+   public:
+    Engine(const std::string& space, const std::string& method, int data_type, int dist_type);
+    ~Engine();
+
+    const std::string& space_name() const { return space_name_; }
+    const std::string& method_name() const { return method_name_; }
+    bool is_u8() const { return space_ == SP_L2SQR_SIFT; }
+    size_t size() const { return ids_.size(); }
+    size_t dim() const { return dim_; }
+    size_t elem_bytes() const { return is_u8() ? 1 : 4; }
+    size_t row_bytes() const { return dim_ * elem_bytes(); }
+    size_t stored_row_bytes() const { return is_u8() ? dim_ + 4 : dim_ * 4; }  // u8 rows carry their norm
+
+    void add_row(const void* data, size_t elem_count, int32_t id);
+    const void* host_row(size_t pos) const;
+    void stored_row(size_t pos, void* dst) const;  // payload as the reference stores it
+    int32_t ext_id(size_t pos) const { return ids_[pos]; }
+    void reset();
+
+    void create_index(const std::vector<std::string>& params);  // nmslib_create_index
+    void set_query_params(const std::vector<std::string>& params);
+    bool index_created() const { return created_; }
+    void finalize();  // upload + build if dirty (nmslib_initialize_pool / lazy)
+
+    // k-NN: device-resident batch (the hot entry) and host convenience wrapper
+    void knn_device(const void* d_queries, size_t nq, size_t elem_count, size_t k, int32_t* d_ids,
+                    float* d_dists, int32_t* d_cnt, hipStream_t stream);
+    void knn_host(const void* queries, size_t nq, size_t elem_count, size_t k, std::vector<int32_t>& ids,
+                  std::vector<float>& dists, std::vector<int32_t>& cnt);
+    float pair_distance(size_t p1, size_t p2);
+
+    void save(const std::string& path, bool save_data);
+    static std::unique_ptr<Engine> load(const std::string& path, int data_type, int dist_type, bool load_data);
+
+    size_t thread_pool_size = 0;
+    size_t memory_usage() const;
+
+    // counters of the last HNSW batch (device pointers)
+    const int32_t* last_ndc() const { return have_counters_ ? ws_ndc_.as<int32_t>() : nullptr; }
+    const int32_t* last_hops() const { return have_counters_ ? ws_hops_.as<int32_t>() : nullptr; }
+    const int32_t* last_hops_up() const { return have_counters_ ? ws_hops_up_.as<int32_t>() : nullptr; }
+
+    double upload_seconds = 0, build_seconds = 0;
+    size_t hbm_bytes() const;
+
+    std::mutex mu;  // serialises finalize + queries on one index
+
+   private:
+    void check_device();
+    void ensure_graph();
+    void upload_rows();
+    void build_graph();
+    void upload_graph();
+    void knn_brute(const void* d_queries, size_t nq, size_t k, int32_t* d_ids, float* d_dists,
+                   int32_t* d_cnt, hipStream_t stream);
+    void knn_hnsw(const void* d_queries, size_t nq, size_t k, int32_t* d_ids, float* d_dists,
+                  int32_t* d_cnt, hipStream_t stream);
+
+    std::string space_name_, method_name_;
+    int space_ = SP_L2;
+    Method method_ = Method::Brute;
+    size_t dim_ = 0;
+    std::vector<int32_t> ids_;
+    std::vector<float> rows_f32_;
+    std::vector<uint8_t> rows_u8_;
+
+    // index-time state
+    bool created_ = false;       // nmslib_create_index was called
+    bool dirty_ = true;          // rows added since the last finalize (device copy stale)
+    bool graph_dirty_ = true;    // rows added since the graph was last built
+    bool loaded_graph_ = false;  // graph came from a file: never rebuild it
+    HnswBuildParams bp_;
+    HostGraph graph_;
+    std::vector<float> graph_rows_;  // rows as stored inside a loaded index (cosine: normalised)
+    int ef_ = 200;                   // the shim's default (nmslib_c.cpp:330)
+    std::string algo_ = "hybrid";
+
+    // device state
+    int device_ = -1;
+    hipStream_t stream_ = nullptr;
+    DevBuf d_rows_, d_aux_, d_ids_, d_links0_, d_up_off_, d_up_links_, d_rownorm_;
+    size_t d_n_ = 0;
+    int ldb_ = 0;
+    HnswDeviceGraph dg_{};
+
+    // workspaces
+    DevBuf ws_q_, ws_qpad_, ws_cand_, ws_cnt_, ws_ids_, ws_dists_, ws_outcnt_, ws_status_, ws_bitset_;
+    DevBuf ws_ndc_, ws_hops_, ws_hops_up_, ws_pair_;
+    bool have_counters_ = false;
+};
+
+}  // namespace gfxknn

@@ -1,0 +1,797 @@
+// Brute-force (sequential-search) path on gfx950.
+//
+// Replaces SeqSearch::Search (src/method/seqsearch.cc:143-150), i.e. one virtual
+// HiddenDistance call per (query, object) + KNNQueue::Push, by
+//   1. bf_select_*  : a tiled Q x B^T contraction on the matrix cores
+//                     (v_mfma_f32_32x32x2_f32 / v_mfma_i32_32x32x32_i8) whose epilogue keeps,
+//                     per (query, row-split), the k' best rows by a ranking score that is
+//                     monotone in the reference distance;
+//   2. bf_rerank    : the reference's own distance formula on those survivors, canonical
+//                     (distance, position) order, top k  (KNNQuery::CheckAndAddToResult,
+//                     knnquery.cc:66-75 + extract_knn_results, nmslib_c.cpp:293-328).
+//
+// Work decomposition: workgroup = 128 queries (4 waves x 32) x one row split.  A wave keeps
+// its 32 queries as the MFMA B operand in registers (D <= 128) and streams base rows through
+// a double-buffered, padded LDS tile (64 rows x <=128 floats per step).  With A = base rows
+// and B = queries, accumulator register r of lane l is the score of query (l & 31) against
+// row (r&3) + 8*(r>>2) + 4*(l>>5): every lane owns ONE query, so the running threshold of
+// that query is a lane-local register and the epilogue is one compare per element.
+// Survivors are appended to a per-(query, split) buffer in HBM (L2-resident); when a buffer
+// nears capacity the owning wave sorts it in LDS, keeps k', and raises the threshold.
+#include "common.cuh"
+#include "kernels.hpp"
+
+namespace gfxknn {
+
+enum BfMode : int { BF_L2 = 0, BF_DOT = 1, BF_COS = 2, BF_L1 = 3, BF_LINF = 4 };
+
+struct BfArgs {
+    const float* base;
+    const float* aux;
+    const float* queries;
+    u64* cand;
+    int* cand_cnt;
+    int n, ldb, nqt, nsplit, rows_per_split, kprime, cap;
+    int kcs;      // floats staged per K-chunk = min(ldb, 128)
+    int nchunks;  // ceil(ldb / 128)
+};
+
+// row handled by accumulator register r of a lane in half h (C/D map of the 32x32 MFMAs)
+__device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// Sort the survivors of one query (wave-cooperative), keep k', return the new threshold as an
+// order-preserving uint32 (0 when fewer than k' survive).
+__device__ __forceinline__ uint32_t compact_candidates(u64* g, int n, int kprime, u64* scratch,
+                                                       int lane, int* cnt_slot) {
+    int P = next_pow2(n < 2 ? 2 : n);
+    for (int i = lane; i < P; i += 64) scratch[i] = (i < n) ? g[i] : 0ull;
+    __builtin_amdgcn_wave_barrier();
+    wave_bitonic_u64(scratch, P, lane, /*descending=*/true);
+    int keep = n < kprime ? n : kprime;
+    for (int i = lane; i < keep; i += 64) g[i] = scratch[i];
+    uint32_t thr = (n >= kprime) ? (uint32_t)(scratch[kprime - 1] >> 32) : 0u;
+    if (lane == 0) *cnt_slot = keep;
+    __builtin_amdgcn_wave_barrier();
+    return thr;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void bf_select_f32_kernel(BfArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, l31 = lane & 31;
+
+    // XCD-aware mapping: blocks b and b+8 share an XCD (round-robin dispatch), so the
+    // nqt query tiles of one row split get ids that differ by multiples of 8 and re-read
+    // that split's rows from the same L2.
+    const int b = blockIdx.x;
+    const int xcd = b & 7, rest = b >> 3;
+    const int qt = rest % a.nqt;
+    const int split = (rest / a.nqt) * 8 + xcd;
+    if (split >= a.nsplit) return;
+
+    const int kcs = a.kcs;
+    const int lds_stride = kcs + 4;  // +16 B pad: conflict-free ds_read_b128 of 32 rows
+    float* tile = reinterpret_cast<float*>(smem);                      // [2][BN][lds_stride]
+    float* auxs = tile + 2 * BF_BN * lds_stride;                       // [2][BN]
+    int* cnt = reinterpret_cast<int*>(auxs + 2 * BF_BN);               // [TQ]
+    u64* scratch_all = reinterpret_cast<u64*>(cnt + BF_TQ);            // [4][cap]
+    u64* scratch = scratch_all + (size_t)wave * a.cap;
+
+    if (tid < BF_TQ) cnt[tid] = 0;
+
+    const int qidx = qt * BF_TQ + wave * 32 + l31;  // this lane's query (row of the padded batch)
+    u64* candq = a.cand + ((size_t)qidx * a.nsplit + split) * a.cap;
+    int* my_cnt = &cnt[wave * 32 + l31];
+
+    const int r_begin = split * a.rows_per_split;
+    const int r_end = min(a.n, r_begin + a.rows_per_split);
+    const int nstages = r_end > r_begin ? (r_end - r_begin + BF_BN - 1) / BF_BN : 0;
+    const int nsteps = nstages * a.nchunks;
+
+    // staging map: 32 threads per row (16 B each), 8 rows per pass, 8 passes = 64 rows
+    const int sc = tid & 31, sr = tid >> 5;
+    f32x4 stg[8];
+    float stg_aux = 0.f;
+
+    auto issue_loads = [&](int step) {
+        const int stage = step / a.nchunks, kc = step - stage * a.nchunks;
+        const int row0 = r_begin + stage * BF_BN;
+        const int col0 = kc * BF_KC + sc * 4;
+        const int kc_len = min(kcs, a.ldb - kc * BF_KC);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int row = row0 + sr + 8 * i;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (sc * 4 < kc_len && row < r_end)
+                v = *reinterpret_cast<const f32x4*>(a.base + (size_t)row * a.ldb + col0);
+            stg[i] = v;
+        }
+        if (kc == 0 && MODE != BF_DOT && MODE != BF_L1 && MODE != BF_LINF && tid < BF_BN) {
+            const int row = row0 + tid;
+            stg_aux = row < r_end ? a.aux[row] : 0.f;
+        }
+    };
+    auto write_lds = [&](int step) {
+        const int stage = step / a.nchunks, kc = step - stage * a.nchunks;
+        float* t = tile + (step & 1) * BF_BN * lds_stride;
+        if (sc * 4 < kcs) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                *reinterpret_cast<f32x4*>(t + (sr + 8 * i) * lds_stride + sc * 4) = stg[i];
+        }
+        if (kc == 0 && MODE != BF_DOT && MODE != BF_L1 && MODE != BF_LINF && tid < BF_BN)
+            auxs[(stage & 1) * BF_BN + tid] = stg_aux;
+    };
+
+    // query fragments: lane (l31, h) holds dims 8t + 4h + {0..3} of its query, t = 0..15
+    f32x4 bq[16];
+    auto load_queries = [&](int kc) {
+        const float* qrow = a.queries + (size_t)qidx * a.ldb + kc * BF_KC + 4 * h;
+        const int kc_len = min(kcs, a.ldb - kc * BF_KC);
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (8 * t < kc_len) v = *reinterpret_cast<const f32x4*>(qrow + 8 * t);
+            bq[t] = v;
+        }
+    };
+
+    constexpr bool kDirect = (MODE == BF_L1 || MODE == BF_LINF);
+    f32x16 acc0, acc1;  // scores of the two 32-row blocks in the MFMA C/D layout
+    // direct (VALU) modes: every lane needs ALL dims of its query; the other half comes from
+    // the partner lane (l ^ 32) once per K-chunk.  qlo/qhi = dims 8t+{0..3} / 8t+{4..7}.
+    f32x4 qlo[kDirect ? 16 : 1], qhi[kDirect ? 16 : 1];
+    auto spread_queries = [&]() {
+        if constexpr (kDirect) {
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                f32x4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = __shfl_xor(bq[t][j], 32, 64);
+                qlo[t] = h == 0 ? bq[t] : o;
+                qhi[t] = h == 0 ? o : bq[t];
+            }
+        }
+    };
+
+    float thr = -INFINITY;      // lane-local threshold of this lane's query
+
+    if (nsteps > 0) {
+        issue_loads(0);
+        write_lds(0);
+    }
+    if (a.nchunks == 1) {
+        load_queries(0);
+        spread_queries();
+    }
+    __syncthreads();
+
+    for (int step = 0; step < nsteps; ++step) {
+        const int stage = step / a.nchunks, kc = step - stage * a.nchunks;
+        const bool have_next = step + 1 < nsteps;
+        if (have_next) issue_loads(step + 1);
+        if (a.nchunks > 1) {
+            load_queries(kc);
+            spread_queries();
+        }
+        const int kc_len = min(kcs, a.ldb - kc * BF_KC);
+        const float* t = tile + (step & 1) * BF_BN * lds_stride;
+
+        if (kc == 0) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                acc0[i] = 0.f;
+                acc1[i] = 0.f;
+            }
+        }
+
+        if constexpr (!kDirect) {
+            const float* ap0 = t + l31 * lds_stride + 4 * h;
+            const float* ap1 = ap0 + 32 * lds_stride;
+#pragma unroll
+            for (int tt = 0; tt < 16; ++tt) {
+                if (8 * tt < kc_len) {
+                    const f32x4 a0 = *reinterpret_cast<const f32x4*>(ap0 + 8 * tt);
+                    const f32x4 a1 = *reinterpret_cast<const f32x4*>(ap1 + 8 * tt);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[0], bq[tt][0], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[0], bq[tt][0], acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[1], bq[tt][1], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[1], bq[tt][1], acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[2], bq[tt][2], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[2], bq[tt][2], acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[3], bq[tt][3], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[3], bq[tt][3], acc1, 0, 0, 0);
+                }
+            }
+        } else {
+            // lanes of one half read the same LDS addresses (broadcast reads); each lane
+            // accumulates full-dimension |a-b| for its own 16 rows per block
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float* ap = t + (blk * 32 + acc_row(r, h)) * lds_stride;
+                    float s = blk == 0 ? acc0[r] : acc1[r];
+#pragma unroll
+                    for (int tt = 0; tt < 16; ++tt) {
+                        if (8 * tt < kc_len) {
+                            const f32x4 alo = *reinterpret_cast<const f32x4*>(ap + 8 * tt);
+                            const f32x4 ahi = *reinterpret_cast<const f32x4*>(ap + 8 * tt + 4);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const float d0 = fabsf(alo[j] - qlo[tt][j]);
+                                const float d1 = fabsf(ahi[j] - qhi[tt][j]);
+                                s = (MODE == BF_L1) ? (s + d0) + d1 : fmaxf(fmaxf(s, d0), d1);
+                            }
+                        }
+                    }
+                    if (blk == 0) acc0[r] = s; else acc1[r] = s;
+                }
+            }
+        }
+
+        if (kc == a.nchunks - 1) {
+            // ---------------- epilogue of this 64-row stage ----------------
+            const float* ax = auxs + (stage & 1) * BF_BN;
+            if constexpr (MODE == BF_L2) {
+                // fold -0.5*||b||^2 in with one more MFMA: A = (aux | 0), B = (1 | 0)
+                const float one = h == 0 ? 1.f : 0.f;
+                const float x0 = h == 0 ? ax[l31] : 0.f;
+                const float x1 = h == 0 ? ax[32 + l31] : 0.f;
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(x0, one, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(x1, one, acc1, 0, 0, 0);
+            }
+            const int row0 = r_begin + stage * BF_BN;
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = blk * 32 + acc_row(r, h);
+                    float s;
+                    s = blk == 0 ? acc0[r] : acc1[r];
+                    if constexpr (kDirect) s = -s;  // smaller distance = better score
+                    if constexpr (MODE == BF_COS) s *= ax[row];
+                    const int pos = row0 + row;
+                    if (pos < r_end && s > thr) {
+                        const int slot = atomicAdd(my_cnt, 1);
+                        if (slot < a.cap) candq[slot] = make_sel_key(f32_ord(s), (uint32_t)pos);
+                    }
+                }
+            }
+            // make this wave's appended keys visible to its own later loads
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            const bool last = stage == nstages - 1;
+            const int c = *my_cnt;
+            const bool need = last || (c > a.cap - BF_BN);
+            u64 m = __ballot(need) & 0xFFFFFFFFull;
+            while (m) {
+                const int q = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                int n = cnt[wave * 32 + q];
+                n = n < a.cap ? n : a.cap;
+                u64* g = a.cand + ((size_t)(qt * BF_TQ + wave * 32 + q) * a.nsplit + split) * a.cap;
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                const uint32_t t_ord =
+                    compact_candidates(g, n, a.kprime, scratch, lane, &cnt[wave * 32 + q]);
+                if (l31 == q && t_ord != 0u) thr = ord_f32(t_ord);
+            }
+        }
+
+        if (have_next) write_lds(step + 1);
+        __syncthreads();
+    }
+
+    __builtin_amdgcn_wave_barrier();
+    if (h == 0) a.cand_cnt[(size_t)qidx * a.nsplit + split] = *my_cnt;
+}
+
+// ---------------------------------------------------------------------------------------
+// uint8 SIFT selection: v_mfma_i32_32x32x32_i8 on bytes re-centred to int8 (x ^ 0x80).
+//   dot(a,b) = dot(a',b') + 128*sum(a) + 128*sum(b) - 128*128*128        (a' = a - 128)
+//   dist     = ||a||^2 + ||b||^2 - 2 dot(a,b)          (distcomp_l2sqr_sift.cc:41-50)
+// so for a fixed query, ranking by  score = 2*dot(a',b') + (256*sum(a) - ||a||^2)  is ranking
+// by -dist, exactly, in int32.  aux[row] = 256*sum(a) - ||a||^2 is precomputed.  Rows of a
+// split arrive in increasing position and the compare is strict, so ties keep the lowest
+// positions: the survivors are exactly the (dist, position)-smallest k.
+// ---------------------------------------------------------------------------------------
+struct BfArgsU8 {
+    const uint8_t* base;   // [n][128]
+    const int32_t* aux;
+    const uint8_t* queries;  // [qpad][128]
+    u64* cand;
+    int* cand_cnt;
+    int n, nqt, nsplit, rows_per_split, kprime, cap;
+};
+
+__global__ __launch_bounds__(256, 2) void bf_select_u8_kernel(BfArgsU8 a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, l31 = lane & 31;
+    const int b = blockIdx.x;
+    const int xcd = b & 7, rest = b >> 3;
+    const int qt = rest % a.nqt;
+    const int split = (rest / a.nqt) * 8 + xcd;
+    if (split >= a.nsplit) return;
+
+    constexpr int LDS_STRIDE = 144;  // 128 B row + 16 B pad (conflict-free b128 reads)
+    uint8_t* tile = reinterpret_cast<uint8_t*>(smem);                       // [2][BN][144]
+    int* auxs = reinterpret_cast<int*>(tile + 2 * BF_BN * LDS_STRIDE);      // [2][BN]
+    int* cnt = auxs + 2 * BF_BN;                                            // [TQ]
+    u64* scratch = reinterpret_cast<u64*>(cnt + BF_TQ) + (size_t)wave * a.cap;
+
+    if (tid < BF_TQ) cnt[tid] = 0;
+    const int qidx = qt * BF_TQ + wave * 32 + l31;
+    u64* candq = a.cand + ((size_t)qidx * a.nsplit + split) * a.cap;
+    int* my_cnt = &cnt[wave * 32 + l31];
+
+    const int r_begin = split * a.rows_per_split;
+    const int r_end = min(a.n, r_begin + a.rows_per_split);
+    const int nstages = r_end > r_begin ? (r_end - r_begin + BF_BN - 1) / BF_BN : 0;
+
+    // staging: 64 rows x 128 B = 512 x 16 B -> 2 per thread; 8 threads per row
+    const int sc = tid & 7, sr = tid >> 3;  // sr in 0..31
+    i32x4 stg[2];
+    int stg_aux = 0;
+    auto issue_loads = [&](int stage) {
+        const int row0 = r_begin + stage * BF_BN;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = row0 + sr + 32 * i;
+            i32x4 v = {0, 0, 0, 0};
+            if (row < r_end) v = *reinterpret_cast<const i32x4*>(a.base + (size_t)row * 128 + sc * 16);
+            stg[i] = v ^ (int)0x80808080;  // re-centre: u8 -> i8
+        }
+        if (tid < BF_BN) stg_aux = (row0 + tid < r_end) ? a.aux[row0 + tid] : 0;
+    };
+    auto write_lds = [&](int stage) {
+        uint8_t* t = tile + (stage & 1) * BF_BN * LDS_STRIDE;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            *reinterpret_cast<i32x4*>(t + (sr + 32 * i) * LDS_STRIDE + sc * 16) = stg[i];
+        if (tid < BF_BN) auxs[(stage & 1) * BF_BN + tid] = stg_aux;
+    };
+
+    // query fragments: 4 K-steps of 32 bytes; lane (l31,h) holds bytes 32*ks + 16*h + {0..15}
+    i32x4 bq[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        i32x4 v = *reinterpret_cast<const i32x4*>(a.queries + (size_t)qidx * 128 + 32 * ks + 16 * h);
+        bq[ks] = v ^ (int)0x80808080;
+    }
+
+    int thr = INT32_MIN;
+    if (nstages > 0) {
+        issue_loads(0);
+        write_lds(0);
+    }
+    __syncthreads();
+
+    for (int stage = 0; stage < nstages; ++stage) {
+        const bool have_next = stage + 1 < nstages;
+        if (have_next) issue_loads(stage + 1);
+        const uint8_t* t = tile + (stage & 1) * BF_BN * LDS_STRIDE;
+        i32x16 acc0, acc1;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            acc0[i] = 0;
+            acc1[i] = 0;
+        }
+        const uint8_t* ap0 = t + l31 * LDS_STRIDE + 16 * h;
+        const uint8_t* ap1 = ap0 + 32 * LDS_STRIDE;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const i32x4 a0 = *reinterpret_cast<const i32x4*>(ap0 + 32 * ks);
+            const i32x4 a1 = *reinterpret_cast<const i32x4*>(ap1 + 32 * ks);
+            acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, bq[ks], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, bq[ks], acc1, 0, 0, 0);
+        }
+        const int* ax = auxs + (stage & 1) * BF_BN;
+        const int row0 = r_begin + stage * BF_BN;
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                // rows 8g+4h+{0..3} of this block: one 16-byte read of their aux values
+                const i32x4 av = *reinterpret_cast<const i32x4*>(ax + blk * 32 + 8 * g + 4 * h);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int r = 4 * g + j;
+                    const int s = 2 * (blk == 0 ? acc0[r] : acc1[r]) + av[j];
+                    const int pos = row0 + blk * 32 + 8 * g + 4 * h + j;
+                    if (pos < r_end && s > thr) {
+                        const int slot = atomicAdd(my_cnt, 1);
+                        if (slot < a.cap) candq[slot] = make_sel_key(i32_ord(s), (uint32_t)pos);
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        const bool last = stage == nstages - 1;
+        const int c = *my_cnt;
+        const bool need = last || (c > a.cap - BF_BN);
+        u64 m = __ballot(need) & 0xFFFFFFFFull;
+        while (m) {
+            const int q = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            int n = cnt[wave * 32 + q];
+            n = n < a.cap ? n : a.cap;
+            u64* g = a.cand + ((size_t)(qt * BF_TQ + wave * 32 + q) * a.nsplit + split) * a.cap;
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            const uint32_t t_ord = compact_candidates(g, n, a.kprime, scratch, lane, &cnt[wave * 32 + q]);
+            if (l31 == q && n >= a.kprime) thr = ord_i32(t_ord);
+        }
+        if (have_next) write_lds(stage + 1);
+        __syncthreads();
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (h == 0) a.cand_cnt[(size_t)qidx * a.nsplit + split] = *my_cnt;
+}
+
+// ---------------------------------------------------------------------------------------
+// Re-rank: one workgroup per query.  Exact reference-formula distance of every survivor,
+// 64-bit keys (distance, position) sorted ascending, first k emitted.
+// ---------------------------------------------------------------------------------------
+struct RerankArgs {
+    const void* base;
+    const void* queries;
+    const u64* cand;
+    const int* cand_cnt;
+    const int32_t* ext_ids;
+    int32_t* out_ids;
+    float* out_dists;
+    int32_t* out_cnt;
+    int space, dim, ldb, k, nsplit, cap, kprime, p2max;
+};
+
+__global__ __launch_bounds__(256) void bf_rerank_kernel(RerankArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    u64* keys = reinterpret_cast<u64*>(smem);                      // [p2max]
+    int* offs = reinterpret_cast<int*>(keys + a.p2max);            // [nsplit + 1]
+    const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    if (tid == 0) {
+        int o = 0;
+        for (int s = 0; s < a.nsplit; ++s) {
+            offs[s] = o;
+            int c = a.cand_cnt[(size_t)q * a.nsplit + s];
+            o += c < a.kprime ? c : a.kprime;
+        }
+        offs[a.nsplit] = o;
+    }
+    __syncthreads();
+    const int total = offs[a.nsplit];
+    // gather survivor positions (low word of keys[] used as a temporary list)
+    for (int idx = tid; idx < a.nsplit * a.kprime; idx += blockDim.x) {
+        const int s = idx / a.kprime, i = idx - s * a.kprime;
+        const int c = offs[s + 1] - offs[s];
+        if (i < c) keys[offs[s] + i] = (u64)sel_key_pos(a.cand[((size_t)q * a.nsplit + s) * a.cap + i]);
+    }
+    __syncthreads();
+    const int P = next_pow2(total < 2 ? 2 : total);
+    for (int j = wave; j < total; j += 4) {
+        const uint32_t pos = (uint32_t)keys[j];
+        u64 key;
+        if (a.space == SP_L2SQR_SIFT) {
+            const uint8_t* row = reinterpret_cast<const uint8_t*>(a.base) + (size_t)pos * 128;
+            const uint8_t* qq = reinterpret_cast<const uint8_t*>(a.queries) + (size_t)q * 128;
+            const int d = wave_exact_distance_u8(row, qq, lane);
+            key = ((u64)i32_ord(d) << 32) | pos;
+        } else {
+            const float* row = reinterpret_cast<const float*>(a.base) + (size_t)pos * a.ldb;
+            const float* qq = reinterpret_cast<const float*>(a.queries) + (size_t)q * a.ldb;
+            const float d = wave_exact_distance_f32(a.space, row, qq, a.dim, lane);
+            key = ((u64)f32_ord(d) << 32) | pos;
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) keys[j] = key;
+    }
+    for (int i = total + tid; i < P; i += blockDim.x) keys[i] = ~0ull;
+    __syncthreads();
+    block_bitonic_u64_asc(keys, P, tid, blockDim.x);
+    const int found = total < a.k ? total : a.k;
+    for (int i = tid; i < a.k; i += blockDim.x) {
+        int32_t id = -1;
+        float d = INFINITY;
+        if (i < found) {
+            const u64 key = keys[i];
+            const uint32_t pos = (uint32_t)key;
+            id = a.ext_ids ? a.ext_ids[pos] : (int32_t)pos;
+            d = (a.space == SP_L2SQR_SIFT) ? (float)ord_i32((uint32_t)(key >> 32))
+                                           : ord_f32((uint32_t)(key >> 32));
+        }
+        a.out_ids[(size_t)q * a.k + i] = id;
+        a.out_dists[(size_t)q * a.k + i] = d;
+    }
+    if (tid == 0 && a.out_cnt) a.out_cnt[q] = found;
+}
+
+// ---------------------------------------------------------------------------------------
+// Small preparation kernels
+// ---------------------------------------------------------------------------------------
+__global__ void row_aux_f32_kernel(const float* base, int n, int ldb, int dim, int space, float* aux) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= n) return;
+    const float* p = base + (size_t)row * ldb;
+    float s = 0.f;
+    for (int d = lane; d < dim; d += 64) s = fmaf(p[d], p[d], s);
+    s = wave_sum(s);
+    if (lane == 0) {
+        float v = 0.f;
+        if (space == SP_L2) v = -0.5f * s;
+        else if (space == SP_COSINE || space == SP_ANGULAR)
+            v = (s < 1.17549435e-38f * 2.0f) ? 0.f : 1.0f / sqrtf(s);
+        aux[row] = v;
+    }
+}
+
+__global__ void row_aux_u8_kernel(const uint8_t* base, int n, int32_t* aux) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= n) return;
+    const uint8_t* p = base + (size_t)row * 128;
+    const int x0 = p[2 * lane], x1 = p[2 * lane + 1];
+    const int sum = wave_sum_i(x0 + x1);
+    const int sq = wave_sum_i(x0 * x0 + x1 * x1);
+    if (lane == 0) aux[row] = 256 * sum - sq;
+}
+
+__global__ void pad_rows_kernel(const uint8_t* src, int rows, int row_bytes, uint8_t* dst, int rows_pad,
+                                int ld_bytes) {
+    const size_t total = (size_t)rows_pad * ld_bytes;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = i / ld_bytes, c = i - r * ld_bytes;
+        dst[i] = (r < (size_t)rows && c < (size_t)row_bytes) ? src[r * row_bytes + c] : (uint8_t)0;
+    }
+}
+
+// hnsw.h:486-497 NormalizeVect: v *= 1/sqrt(sum v^2) unless the sum is exactly 0
+__global__ void normalize_rows_kernel(float* rows, int n, int ld, int dim) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= n) return;
+    float* p = rows + (size_t)row * ld;
+    float s = 0.f;
+    for (int d = lane; d < dim; d += 64) s = fmaf(p[d], p[d], s);
+    s = wave_sum(s);
+    if (s != 0.0f) {
+        const float inv = 1.0f / sqrtf(s);
+        for (int d = lane; d < dim; d += 64) p[d] *= inv;
+    }
+}
+
+__global__ void pair_distance_kernel(int space, const void* a, const void* b, int dim, float* out) {
+    const int lane = threadIdx.x & 63;
+    float d;
+    if (space == SP_L2SQR_SIFT)
+        d = (float)wave_exact_distance_u8((const uint8_t*)a, (const uint8_t*)b, lane);
+    else
+        d = wave_exact_distance_f32(space, (const float*)a, (const float*)b, dim, lane);
+    if (lane == 0) *out = d;
+}
+
+// per-shard top-k lists -> global top-k by (distance, id); one wave per query
+__global__ void merge_topk_kernel(const float* dists_in, const int32_t* ids_in, int nshards, int nq,
+                                  int k, float* dists_out, int32_t* ids_out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    u64* keys = reinterpret_cast<u64*>(smem);
+    const int q = blockIdx.x, tid = threadIdx.x;
+    const int total = nshards * k;
+    const int P = next_pow2(total < 2 ? 2 : total);
+    for (int i = tid; i < P; i += blockDim.x) {
+        u64 key = ~0ull;
+        if (i < total) {
+            const int s = i / k, j = i - s * k;
+            const size_t off = ((size_t)s * nq + q) * k + j;
+            const int32_t id = ids_in[off];
+            if (id >= 0) key = ((u64)f32_ord(dists_in[off]) << 32) | (uint32_t)id;
+        }
+        keys[i] = key;
+    }
+    __syncthreads();
+    block_bitonic_u64_asc(keys, P, tid, blockDim.x);
+    for (int i = tid; i < k; i += blockDim.x) {
+        const u64 key = keys[i];
+        const bool ok = key != ~0ull;
+        ids_out[(size_t)q * k + i] = ok ? (int32_t)(uint32_t)key : -1;
+        dists_out[(size_t)q * k + i] = ok ? ord_f32((uint32_t)(key >> 32)) : INFINITY;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Host side
+// ---------------------------------------------------------------------------------------
+static int host_next_pow2(int v) {
+    int p = 1;
+    while (p < v) p <<= 1;
+    return p;
+}
+
+BfPlan bf_make_plan(int n, int dim, int nq, int k, bool is_u8) {
+    BfPlan p{};
+    p.nq = nq;
+    p.nqt = (nq + BF_TQ - 1) / BF_TQ;
+    p.qpad = p.nqt * BF_TQ;
+    p.n = n;
+    p.ldb = is_u8 ? 128 : f32_row_stride(dim);
+    // float scores are ranked in the Q.B^T form, whose rounding differs from the reference's
+    // direct formula: keep a few more than k per split and let the exact re-rank decide.
+    p.kprime = is_u8 ? k : k + (k / 8 > 4 ? k / 8 : 4);
+    p.cap = host_next_pow2(2 * p.kprime + BF_BN);
+    if (p.cap < 256) p.cap = 256;
+    // splits: fill the chip (>= 512 workgroups of 2/CU), keep >= 2 stages per split, and bound
+    // the re-rank sort (nsplit * kprime keys in LDS)
+    int want = (512 + p.nqt - 1) / p.nqt;
+    int by_rows = (n + 2 * BF_BN - 1) / (2 * BF_BN);
+    int by_sort = 4096 / p.kprime;
+    int ns = want < by_rows ? want : by_rows;
+    if (ns > by_sort) ns = by_sort;
+    if (ns > 64) ns = 64;
+    ns = (ns + 7) / 8 * 8;
+    if (ns < 8) ns = 8;
+    p.nsplit = ns;
+    int rps = (n + ns - 1) / ns;
+    p.rows_per_split = (rps + BF_BN - 1) / BF_BN * BF_BN;
+    if (p.rows_per_split < BF_BN) p.rows_per_split = BF_BN;
+    p.p2max = host_next_pow2(p.nsplit * p.kprime);
+    const int kcs = p.ldb < BF_KC ? p.ldb : BF_KC;
+    if (is_u8)
+        p.lds_select = 2 * BF_BN * 144 + 2 * BF_BN * 4 + BF_TQ * 4 + 4 * (size_t)p.cap * 8;
+    else
+        p.lds_select = (size_t)2 * BF_BN * (kcs + 4) * 4 + 2 * BF_BN * 4 + BF_TQ * 4 + 4 * (size_t)p.cap * 8;
+    p.lds_rerank = (size_t)p.p2max * 8 + (p.nsplit + 1) * 4 + 16;
+    return p;
+}
+
+template <int MODE>
+static hipError_t launch_select_mode(const BfPlan& p, const BfArgs& a, hipStream_t s) {
+    auto kern = bf_select_f32_kernel<MODE>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_select);
+    if (e != hipSuccess) return e;
+    const int grid = 8 * p.nqt * (p.nsplit / 8);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), p.lds_select, s, a);
+    return hipGetLastError();
+}
+
+static BfArgs make_args(const BfPlan& p, const float* base, const float* aux, const float* q, u64* cand,
+                        int* cnt) {
+    BfArgs a{};
+    a.base = base;
+    a.aux = aux;
+    a.queries = q;
+    a.cand = cand;
+    a.cand_cnt = cnt;
+    a.n = p.n;
+    a.ldb = p.ldb;
+    a.nqt = p.nqt;
+    a.nsplit = p.nsplit;
+    a.rows_per_split = p.rows_per_split;
+    a.kprime = p.kprime;
+    a.cap = p.cap;
+    a.kcs = p.ldb < BF_KC ? p.ldb : BF_KC;
+    a.nchunks = (p.ldb + BF_KC - 1) / BF_KC;
+    return a;
+}
+
+hipError_t launch_bf_select_f32(const BfPlan& p, int space, const float* base, const float* aux,
+                                const float* queries_padded, unsigned long long* cand, int* cand_cnt,
+                                hipStream_t s) {
+    BfArgs a = make_args(p, base, aux, queries_padded, cand, cand_cnt);
+    switch (space) {
+        case SP_L2: return launch_select_mode<BF_L2>(p, a, s);
+        case SP_NEGDOT: return launch_select_mode<BF_DOT>(p, a, s);
+        case SP_COSINE:
+        case SP_ANGULAR: return launch_select_mode<BF_COS>(p, a, s);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_bf_select_direct_f32(const BfPlan& p, int space, const float* base,
+                                       const float* queries_padded, unsigned long long* cand,
+                                       int* cand_cnt, hipStream_t s) {
+    BfArgs a = make_args(p, base, nullptr, queries_padded, cand, cand_cnt);
+    if (space == SP_L1) return launch_select_mode<BF_L1>(p, a, s);
+    if (space == SP_LINF) return launch_select_mode<BF_LINF>(p, a, s);
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_bf_select_u8(const BfPlan& p, const uint8_t* base, const int32_t* aux,
+                               const uint8_t* queries_padded, unsigned long long* cand, int* cand_cnt,
+                               hipStream_t s) {
+    BfArgsU8 a{};
+    a.base = base;
+    a.aux = aux;
+    a.queries = queries_padded;
+    a.cand = cand;
+    a.cand_cnt = cand_cnt;
+    a.n = p.n;
+    a.nqt = p.nqt;
+    a.nsplit = p.nsplit;
+    a.rows_per_split = p.rows_per_split;
+    a.kprime = p.kprime;
+    a.cap = p.cap;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bf_select_u8_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_select);
+    if (e != hipSuccess) return e;
+    const int grid = 8 * p.nqt * (p.nsplit / 8);
+    hipLaunchKernelGGL(bf_select_u8_kernel, dim3(grid), dim3(256), p.lds_select, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_bf_rerank(const BfPlan& p, int space, int dim, int k, const void* base,
+                            const void* queries_padded, const unsigned long long* cand,
+                            const int* cand_cnt, const int32_t* ext_ids, int32_t* out_ids,
+                            float* out_dists, int32_t* out_cnt, hipStream_t s) {
+    RerankArgs a{};
+    a.base = base;
+    a.queries = queries_padded;
+    a.cand = cand;
+    a.cand_cnt = cand_cnt;
+    a.ext_ids = ext_ids;
+    a.out_ids = out_ids;
+    a.out_dists = out_dists;
+    a.out_cnt = out_cnt;
+    a.space = space;
+    a.dim = dim;
+    a.ldb = p.ldb;
+    a.k = k;
+    a.nsplit = p.nsplit;
+    a.cap = p.cap;
+    a.kprime = p.kprime;
+    a.p2max = p.p2max;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bf_rerank_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_rerank);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(bf_rerank_kernel, dim3(p.nq), dim3(256), p.lds_rerank, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_row_aux_f32(const float* base, int n, int ldb, int dim, int space, float* aux,
+                              hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(row_aux_f32_kernel, dim3((n + 3) / 4), dim3(256), 0, s, base, n, ldb, dim, space, aux);
+    return hipGetLastError();
+}
+hipError_t launch_row_aux_u8(const uint8_t* base, int n, int32_t* aux, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(row_aux_u8_kernel, dim3((n + 3) / 4), dim3(256), 0, s, base, n, aux);
+    return hipGetLastError();
+}
+hipError_t launch_pad_rows(const void* src, int rows, int dim, void* dst, int rows_pad, int ld,
+                           int elem_bytes, hipStream_t s) {
+    const size_t total = (size_t)rows_pad * ld * elem_bytes;
+    if (total == 0) return hipSuccess;
+    int grid = (int)((total + 255) / 256);
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(pad_rows_kernel, dim3(grid), dim3(256), 0, s, (const uint8_t*)src, rows,
+                       dim * elem_bytes, (uint8_t*)dst, rows_pad, ld * elem_bytes);
+    return hipGetLastError();
+}
+hipError_t launch_normalize_rows(float* rows, int n, int ld, int dim, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(normalize_rows_kernel, dim3((n + 3) / 4), dim3(256), 0, s, rows, n, ld, dim);
+    return hipGetLastError();
+}
+hipError_t launch_pair_distance(int space, const void* a, const void* b, int dim, float* out,
+                                hipStream_t s) {
+    hipLaunchKernelGGL(pair_distance_kernel, dim3(1), dim3(64), 0, s, space, a, b, dim, out);
+    return hipGetLastError();
+}
+hipError_t launch_merge_topk(const float* dists_in, const int32_t* ids_in, int nshards, int nq, int k,
+                             float* dists_out, int32_t* ids_out, hipStream_t s) {
+    const int P = host_next_pow2(nshards * k < 2 ? 2 : nshards * k);
+    const size_t lds = (size_t)P * 8;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(merge_topk_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(merge_topk_kernel, dim3(nq), dim3(256), lds, s, dists_in, ids_in, nshards, nq, k,
+                       dists_out, ids_out);
+    return hipGetLastError();
+}
+
+}  // namespace gfxknn

@@ -1,0 +1,562 @@
+// HNSW search on gfx950: one wavefront (64 lanes) per query.
+//
+// Restates Hnsw::SearchV1Merge (src/method/hnsw_distfunc_opt.cc:152-283) and its generic twin
+// baseSearchAlgorithmV1Merge (src/method/hnsw.cc:1174-1300) step for step:
+//   1. greedy descent through the upper levels (:173-198);
+//   2. level-0 best-first over a bounded sorted array (SortArrBI, include/sort_arr_bi.h) of
+//      max(ef, k) items: expand the first unused item, evaluate its unvisited neighbours,
+//      keep those with d < topKey (or while fewer than ef items), insert them in ascending
+//      order with SortArrBI::push_or_replace_non_empty_exp semantics (:159-199);
+//   3. emit the first k items (:276-281) through KNNQueue ordering (knnqueue.h:55-64).
+// What changes is the execution shape: the <=32 neighbours of one expansion are a frontier
+// batch.  Their ids are filtered through a visited set kept in LDS (open-addressing hash,
+// exact) and the unvisited rows are gathered from HBM together - 8 lanes per row, 16 bytes
+// per lane per step, up to 32 rows in flight per wave - with the distance fused into the
+// gather and an 8-lane shuffle reduction.  The sorted array lives in LDS and is shifted by
+// all lanes at once.  ndc / hops counters feed the roofline.
+#include "common.cuh"
+#include "kernels.hpp"
+
+namespace gfxknn {
+
+struct HnswArgs {
+    HnswDeviceGraph g;
+    const void* queries;
+    uint32_t* bitset;
+    size_t bitset_words;
+    int32_t* out_ids;
+    float* out_dists;
+    int32_t* out_cnt;
+    int32_t* out_ndc;
+    int32_t* out_hops;
+    int32_t* out_hops_up;
+    int32_t* status;
+    int nq, k, ef, cap;
+    int capa;  // cap rounded up to a multiple of 4 (keeps the LDS carve-up 16-byte aligned)
+    int table_size, table_shift;
+};
+
+constexpr uint32_t HT_EMPTY = 0xFFFFFFFFu;
+constexpr int SA_EMAX = 16;  // sorted array up to 64*16 = 1024 items
+
+template <int SPACE>
+struct DistTraits {
+    static constexpr bool kU8 = (SPACE == SP_L2SQR_SIFT);
+    static constexpr bool kThree = (SPACE == SP_COSINE || SPACE == SP_ANGULAR);
+    static constexpr bool kMax = (SPACE == SP_LINF);
+};
+
+template <int SPACE>
+__device__ __forceinline__ void accum4(const f32x4& q, const f32x4& b, float& s0, float& s1, float& s2) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if constexpr (SPACE == SP_L2SQR || SPACE == SP_L2) {
+            const float t = q[j] - b[j];
+            s0 = fmaf(t, t, s0);
+        } else if constexpr (SPACE == SP_L1) {
+            s0 += fabsf(q[j] - b[j]);
+        } else if constexpr (SPACE == SP_LINF) {
+            s0 = fmaxf(s0, fabsf(q[j] - b[j]));
+        } else if constexpr (SPACE == SP_NORMCOS || SPACE == SP_NEGDOT) {
+            s0 = fmaf(q[j], b[j], s0);
+        } else {  // cosine / angular on raw rows: dot, |row|^2, |query|^2
+            s0 = fmaf(b[j], q[j], s0);
+            s1 = fmaf(b[j], b[j], s1);
+            s2 = fmaf(q[j], q[j], s2);
+        }
+    }
+}
+
+template <int SPACE>
+__device__ __forceinline__ float finish_dist(float s0, float s1, float s2) {
+    if constexpr (SPACE == SP_L2) return sqrtf(s0);
+    else if constexpr (SPACE == SP_NEGDOT) return -s0;
+    else if constexpr (SPACE == SP_NORMCOS) {
+        const float c = fmaxf(-1.0f, fminf(1.0f, s0));
+        return fmaxf(0.0f, 1.0f - c);
+    } else if constexpr (SPACE == SP_COSINE) return fmaxf(0.0f, 1.0f - normdot_finish(s0, s1, s2));
+    else if constexpr (SPACE == SP_ANGULAR) return acosf(normdot_finish(s0, s1, s2));
+    else return s0;
+}
+
+__device__ __forceinline__ float group8_sum(float v) {
+    v += __shfl_xor(v, 4, 64);
+    v += __shfl_xor(v, 2, 64);
+    v += __shfl_xor(v, 1, 64);
+    return v;
+}
+__device__ __forceinline__ float group8_max(float v) {
+    v = fmaxf(v, __shfl_xor(v, 4, 64));
+    v = fmaxf(v, __shfl_xor(v, 2, 64));
+    v = fmaxf(v, __shfl_xor(v, 1, 64));
+    return v;
+}
+__device__ __forceinline__ int group8_sum_i(int v) {
+    v += __shfl_xor(v, 4, 64);
+    v += __shfl_xor(v, 2, 64);
+    v += __shfl_xor(v, 1, 64);
+    return v;
+}
+
+// Distances of the query to the m rows listed in nbr[0..m) -> nd[0..m).
+// 8 lanes per row; 8 rows per pass; 4 passes issued together (32 rows in flight).
+template <int SPACE>
+__device__ __forceinline__ void frontier_distances(const HnswDeviceGraph& g, const float* qv,
+                                                   const uint8_t* qb, int qnorm, const int* nbr,
+                                                   float* nd, int m, int lane) {
+    const int g8 = lane >> 3, sub = lane & 7;
+    for (int base_i = 0; base_i < m; base_i += 32) {
+        int ids[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int idx = base_i + p * 8 + g8;
+            ids[p] = idx < m ? nbr[idx] : -1;
+        }
+        if constexpr (DistTraits<SPACE>::kU8) {
+            // 128-byte rows: one 16-byte load per lane; exact integer n1 + n2 - 2*dot
+            const i32x4 qq = *reinterpret_cast<const i32x4*>(qb + sub * 16);
+            int dots[4];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                int dsum = 0;
+                if (ids[p] >= 0) {
+                    const i32x4 bb = *reinterpret_cast<const i32x4*>(
+                        reinterpret_cast<const uint8_t*>(g.rows) + (size_t)ids[p] * 128 + sub * 16);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) dsum = __builtin_amdgcn_udot4(qq[j], bb[j], dsum, false);
+                }
+                dots[p] = dsum;
+            }
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int dot = group8_sum_i(dots[p]);
+                const int idx = base_i + p * 8 + g8;
+                if (sub == 0 && idx < m) nd[idx] = (float)(g.row_norm[ids[p]] + qnorm - 2 * dot);
+            }
+        } else {
+            float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+            const float* rows = reinterpret_cast<const float*>(g.rows);
+#pragma unroll 4
+            for (int d = sub * 4; d < g.ldv; d += 32) {
+                const f32x4 qq = *reinterpret_cast<const f32x4*>(qv + d);
+                f32x4 bb[4];
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    bb[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (ids[p] >= 0) bb[p] = *reinterpret_cast<const f32x4*>(rows + (size_t)ids[p] * g.ldv + d);
+                }
+#pragma unroll
+                for (int p = 0; p < 4; ++p) accum4<SPACE>(qq, bb[p], s0[p], s1[p], s2[p]);
+            }
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                float r0, r1 = 0.f, r2 = 0.f;
+                if constexpr (DistTraits<SPACE>::kMax) r0 = group8_max(s0[p]);
+                else r0 = group8_sum(s0[p]);
+                if constexpr (DistTraits<SPACE>::kThree) {
+                    r1 = group8_sum(s1[p]);
+                    r2 = group8_sum(s2[p]);
+                }
+                const int idx = base_i + p * 8 + g8;
+                if (sub == 0 && idx < m) nd[idx] = finish_dist<SPACE>(r0, r1, r2);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+template <int SPACE, bool BITSET>
+__global__ __launch_bounds__(64) void hnsw_search_kernel(HnswArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const HnswDeviceGraph& g = a.g;
+    const int q = blockIdx.x, lane = threadIdx.x;
+    constexpr bool kU8 = DistTraits<SPACE>::kU8;
+
+    // ---- LDS carve-up (all offsets multiples of 16 bytes) ----
+    float* keys = reinterpret_cast<float*>(smem);                  // [capa]
+    int* idu = reinterpret_cast<int*>(keys + a.capa);              // [capa]  id | used<<31
+    const int qfloats = kU8 ? 32 : g.ldv;
+    float* qv = reinterpret_cast<float*>(idu + a.capa);            // [ldv] (u8: 128 bytes)
+    int* nbr = reinterpret_cast<int*>(qv + qfloats);               // [64]
+    float* nd = reinterpret_cast<float*>(nbr + 64);                // [64]
+    float* sk = nd + 64;                                           // [64] accepted keys, sorted
+    int* si = reinterpret_cast<int*>(sk + 64);                     // [64] accepted ids
+    uint32_t* table = reinterpret_cast<uint32_t*>(si + 64);        // [table_size]
+    uint32_t* bits = BITSET ? a.bitset + (size_t)q * a.bitset_words : nullptr;
+
+    // ---- stage the query ----
+    int qnorm = 0;
+    if constexpr (kU8) {
+        const uint8_t* src = reinterpret_cast<const uint8_t*>(a.queries) + (size_t)q * 128;
+        const int x0 = src[2 * lane], x1 = src[2 * lane + 1];
+        reinterpret_cast<uint8_t*>(qv)[2 * lane] = (uint8_t)x0;
+        reinterpret_cast<uint8_t*>(qv)[2 * lane + 1] = (uint8_t)x1;
+        qnorm = wave_sum_i(x0 * x0 + x1 * x1);
+    } else {
+        const float* src = reinterpret_cast<const float*>(a.queries) + (size_t)q * g.dim;
+        float ss = 0.f;
+        for (int d = lane; d < g.ldv; d += 64) {
+            const float v = d < g.dim ? src[d] : 0.f;
+            qv[d] = v;
+            ss = fmaf(v, v, ss);
+        }
+        if (g.normalize_query) {  // hnsw_distfunc_opt.cc:160-162
+            ss = wave_sum(ss);
+            if (ss != 0.0f) {
+                const float inv = 1.0f / sqrtf(ss);
+                for (int d = lane; d < g.dim; d += 64) qv[d] *= inv;
+            }
+        }
+    }
+    if constexpr (!BITSET) {
+        for (int i = lane; i < a.table_size; i += 64) table[i] = HT_EMPTY;
+    }
+    __builtin_amdgcn_wave_barrier();
+    const uint8_t* qb = reinterpret_cast<const uint8_t*>(qv);
+
+    int ndc = 0, hops = 0, hops_up = 0, nvisited = 0;
+    bool overflow = false;
+
+    // visited test-and-set: true when id was NOT visited before (exact)
+    auto visit = [&](uint32_t id) -> bool {
+        if constexpr (BITSET) {
+            const uint32_t bit = 1u << (id & 31);
+            const uint32_t old = atomicOr(&bits[id >> 5], bit);
+            return (old & bit) == 0;
+        } else {
+            uint32_t hsh = (id * 2654435761u) >> a.table_shift;
+            const uint32_t mask = (uint32_t)a.table_size - 1u;
+            for (int probe = 0; probe < a.table_size; ++probe) {
+                const uint32_t old = atomicCAS(&table[hsh], HT_EMPTY, id);
+                if (old == HT_EMPTY) return true;
+                if (old == id) return false;
+                hsh = (hsh + 1) & mask;
+            }
+            return false;
+        }
+    };
+
+    if (g.n == 0) {
+        for (int i = lane; i < a.k; i += 64) {
+            a.out_ids[(size_t)q * a.k + i] = -1;
+            a.out_dists[(size_t)q * a.k + i] = INFINITY;
+        }
+        if (lane == 0) {
+            a.out_cnt[q] = 0;
+            if (a.out_ndc) a.out_ndc[q] = 0;
+            if (a.out_hops) a.out_hops[q] = 0;
+            if (a.out_hops_up) a.out_hops_up[q] = 0;
+            if (a.status) a.status[q] = 0;
+        }
+        return;
+    }
+
+    // ---- entry point + greedy descent (hnsw_distfunc_opt.cc:168-198) ----
+    int cur = g.enterpoint;
+    if (lane == 0) nbr[0] = cur;
+    __builtin_amdgcn_wave_barrier();
+    frontier_distances<SPACE>(g, qv, qb, qnorm, nbr, nd, 1, lane);
+    float curdist = nd[0];
+    ndc += 1;
+    for (int lvl = g.maxlevel; lvl > 0; --lvl) {
+        bool changed = true;
+        while (changed) {
+            changed = false;
+            const int64_t off = g.up_off[cur] + (int64_t)(lvl - 1) * (g.maxM + 1);
+            const int v = (lane <= g.maxM) ? g.up_links[off + lane] : 0;
+            const int cntl = __builtin_amdgcn_readfirstlane(v);
+            const int nb = __shfl(v, lane + 1, 64);
+            if (lane < cntl) nbr[lane] = nb;
+            __builtin_amdgcn_wave_barrier();
+            hops_up++;
+            if (cntl > 0) {
+                frontier_distances<SPACE>(g, qv, qb, qnorm, nbr, nd, cntl, lane);
+                ndc += cntl;
+                // sequential "if (d < curdist)" scan == first index attaining the minimum
+                u64 key = ~0ull;
+                if (lane < cntl) key = ((u64)f32_ord(nd[lane]) << 32) | (uint32_t)lane;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    const u64 other = __shfl_xor(key, o, 64);
+                    key = other < key ? other : key;
+                }
+                const float dmin = ord_f32((uint32_t)(key >> 32));
+                if (dmin < curdist) {
+                    curdist = dmin;
+                    cur = nbr[(uint32_t)key];
+                    changed = true;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+
+    // ---- level 0 (hnsw_distfunc_opt.cc:200-274) ----
+    int n = 1;
+    if (lane == 0) {
+        keys[0] = curdist;
+        idu[0] = cur;
+    }
+    {
+        bool fresh = false;
+        if (lane == 0) fresh = visit((uint32_t)cur);
+        (void)fresh;
+        nvisited = 1;
+    }
+    __builtin_amdgcn_wave_barrier();
+
+    while (true) {
+        const int lim = n < a.ef ? n : a.ef;
+        // first unused item
+        int fu = n;
+#pragma unroll
+        for (int e = 0; e < SA_EMAX; ++e) {
+            if (e * 64 < n && fu == n) {
+                const int i = lane + 64 * e;
+                const bool un = i < n && idu[i] >= 0;
+                const u64 mk = __ballot(un);
+                if (mk) fu = 64 * e + (__ffsll((long long)mk) - 1);
+            }
+        }
+        if (fu >= lim) break;
+        const int c = idu[fu] & 0x7FFFFFFF;
+        if (lane == 0) idu[fu] |= (int)0x80000000;
+        hops++;
+        const float topKey = keys[n - 1];
+        const int size0 = n;
+
+        // adjacency of c: [count][ids...]
+        const int v = (lane <= g.maxM0) ? g.links0[(size_t)c * (g.maxM0 + 1) + lane] : 0;
+        const int cntn = __builtin_amdgcn_readfirstlane(v);
+        const int nb = __shfl(v, lane + 1, 64);
+        bool isn = false;
+        if (lane < cntn) isn = visit((uint32_t)nb);
+        const u64 nmask = __ballot(isn);
+        const int m = __popcll(nmask);
+        if (isn) nbr[__popcll(nmask & ((1ull << lane) - 1ull))] = nb;
+        nvisited += m;
+        if (!BITSET && nvisited > (a.table_size - (a.table_size >> 3))) {
+            overflow = true;  // visited table nearly full: give up, the host re-runs with a bitset
+            break;
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (m == 0) continue;
+        ndc += m;
+        frontier_distances<SPACE>(g, qv, qb, qnorm, nbr, nd, m, lane);
+
+        // accept d < topKey || size < ef   (:240)
+        float dj = INFINITY;
+        int idj = -1;
+        bool acc = false;
+        if (lane < m) {
+            dj = nd[lane];
+            idj = nbr[lane];
+            acc = (dj < topKey) || (size0 < a.ef);
+        }
+        const u64 amask = __ballot(acc);
+        const int m2 = __popcll(amask);
+        if (m2 == 0) continue;
+        // ascending order of the accepted items (std::sort, :251); ties keep list order
+        int rank = 0;
+        for (u64 mm = amask; mm;) {
+            const int j = __ffsll((long long)mm) - 1;
+            mm &= mm - 1;
+            const float dother = __shfl(dj, j, 64);
+            rank += (dother < dj || (dother == dj && j < lane)) ? 1 : 0;
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (acc) {
+            sk[rank] = dj;
+            si[rank] = idj;
+        }
+        __builtin_amdgcn_wave_barrier();
+
+        // SortArrBI::push_or_replace_non_empty_exp for each, in order (sort_arr_bi.h:159-199)
+        for (int t = 0; t < m2; ++t) {
+            const float key = sk[t];
+            const int id = si[t];
+            const float lastk = keys[n - 1];
+            if (lastk <= key) {
+                if (n < a.cap) {
+                    if (lane == 0) {
+                        keys[n] = key;
+                        idu[n] = id;
+                    }
+                    n++;
+                }
+            } else {
+                // exponential probe from the tail, then lower_bound inside [curr, prev): with
+                // runs of equal keys this lands where the reference lands (sort_arr_bi.h:172-186)
+                int curr = n - 1, prev = curr, dstep = 1;
+                while (curr > 0 && keys[curr] > key) {
+                    prev = curr;
+                    curr -= dstep;
+                    dstep *= 2;
+                    if (dstep > curr) dstep = curr;
+                }
+                int p = curr;
+                if (curr < prev) {
+#pragma unroll
+                    for (int e = 0; e < SA_EMAX; ++e) {
+                        if (curr + e * 64 < prev) {
+                            const int i = curr + lane + 64 * e;
+                            p += __popcll(__ballot(i < prev && keys[i] < key));
+                        }
+                    }
+                }
+                const int newn = n < a.cap ? n + 1 : a.cap;
+                float rk[SA_EMAX];
+                int ri[SA_EMAX];
+#pragma unroll
+                for (int e = 0; e < SA_EMAX; ++e) {
+                    if (e * 64 < newn) {
+                        const int i = lane + 64 * e;
+                        if (i > p && i < newn) {
+                            rk[e] = keys[i - 1];
+                            ri[e] = idu[i - 1];
+                        }
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int e = 0; e < SA_EMAX; ++e) {
+                    if (e * 64 < newn) {
+                        const int i = lane + 64 * e;
+                        if (i > p && i < newn) {
+                            keys[i] = rk[e];
+                            idu[i] = ri[e];
+                        }
+                    }
+                }
+                if (lane == 0) {
+                    keys[p] = key;
+                    idu[p] = id;
+                }
+                n = newn;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+
+    // ---- results: first k items, ties ordered by internal id (KNNQueue holds
+    //      pair<dist, Object*> and data_rearranged_ addresses grow with the id) ----
+    const int kk = overflow ? 0 : (a.k < n ? a.k : n);
+    for (int i = lane; i < a.k; i += 64) {
+        if (i < kk) {
+            const float ki = keys[i];
+            const int id = idu[i] & 0x7FFFFFFF;
+            int r = i;
+            for (int j = i - 1; j >= 0 && keys[j] == ki; --j) r -= ((idu[j] & 0x7FFFFFFF) > id) ? 1 : 0;
+            for (int j = i + 1; j < kk && keys[j] == ki; ++j) r += ((idu[j] & 0x7FFFFFFF) < id) ? 1 : 0;
+            a.out_ids[(size_t)q * a.k + r] = g.ext_ids ? g.ext_ids[id] : id;
+            a.out_dists[(size_t)q * a.k + r] = ki;
+        } else {
+            a.out_ids[(size_t)q * a.k + i] = -1;
+            a.out_dists[(size_t)q * a.k + i] = INFINITY;
+        }
+    }
+    if (lane == 0) {
+        a.out_cnt[q] = kk;
+        if (a.out_ndc) a.out_ndc[q] = ndc;
+        if (a.out_hops) a.out_hops[q] = hops;
+        if (a.out_hops_up) a.out_hops_up[q] = hops_up;
+        if (a.status) a.status[q] = overflow ? 1 : 0;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Host side
+// ---------------------------------------------------------------------------------------
+static int ilog2(int v) {
+    int l = 0;
+    while ((1 << l) < v) ++l;
+    return l;
+}
+
+HnswSearchPlan hnsw_make_plan(const HnswDeviceGraph& g, int nq, int k, int ef, bool force_bitset) {
+    HnswSearchPlan p{};
+    p.nq = nq;
+    p.k = k;
+    p.ef = ef;
+    p.cap = ef > k ? ef : k;
+    const bool u8 = g.space == SP_L2SQR_SIFT;
+    const size_t fixed = (size_t)((p.cap + 3) & ~3) * 8 + (u8 ? 128 : (size_t)g.ldv * 4) + 4 * 64 * 4;
+    // expected visited nodes ~ (maxM0 * expansions); expansions ~ ef.  Size the table for 2x that
+    // and never let LDS push residency below 4 waves per CU (160 KB / 4).
+    int want = 1 << ilog2((g.maxM0 > 0 ? g.maxM0 : 32) * p.cap * 2);
+    if (want < 2048) want = 2048;
+    const size_t budget = 40 * 1024;
+    while ((size_t)want * 4 + fixed > budget && want > 2048) want >>= 1;
+    // ~18 distance evaluations per unit of ef on 1M-row graphs: beyond half load
+    // the exact hash set is replaced by a per-query bitset in HBM
+    if (force_bitset || 18 * p.cap > want / 2 || (size_t)want * 4 + fixed > 64 * 1024) {
+        p.table_size = 0;
+        p.bitset_words = ((size_t)g.n + 31) / 32;
+        p.lds_bytes = fixed + 16;
+    } else {
+        p.table_size = want;
+        p.bitset_words = 0;
+        p.lds_bytes = fixed + (size_t)want * 4;
+    }
+    return p;
+}
+
+template <int SPACE>
+static hipError_t launch_space(const HnswArgs& a, const HnswSearchPlan& p, hipStream_t s) {
+    hipError_t e;
+    if (p.table_size == 0) {
+        auto kern = hnsw_search_kernel<SPACE, true>;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, dim3(a.nq), dim3(64), p.lds_bytes, s, a);
+    } else {
+        auto kern = hnsw_search_kernel<SPACE, false>;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, dim3(a.nq), dim3(64), p.lds_bytes, s, a);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_hnsw_search(const HnswDeviceGraph& g, const HnswSearchPlan& p, const void* queries,
+                              uint32_t* bitset, int32_t* out_ids, float* out_dists, int32_t* out_cnt,
+                              int32_t* out_ndc, int32_t* out_hops, int32_t* out_hops_up,
+                              int32_t* status, hipStream_t s) {
+    if (p.nq == 0) return hipSuccess;
+    if (p.cap > 64 * SA_EMAX || g.maxM0 > 62 || g.maxM > 62) return hipErrorInvalidValue;
+    HnswArgs a{};
+    a.g = g;
+    a.queries = queries;
+    a.bitset = bitset;
+    a.bitset_words = p.bitset_words;
+    a.out_ids = out_ids;
+    a.out_dists = out_dists;
+    a.out_cnt = out_cnt;
+    a.out_ndc = out_ndc;
+    a.out_hops = out_hops;
+    a.out_hops_up = out_hops_up;
+    a.status = status;
+    a.nq = p.nq;
+    a.k = p.k;
+    a.ef = p.ef;
+    a.cap = p.cap;
+    a.capa = (p.cap + 3) & ~3;
+    a.table_size = p.table_size;
+    a.table_shift = p.table_size ? 32 - ilog2(p.table_size) : 0;
+    switch (g.space) {
+        case SP_L2SQR: return launch_space<SP_L2SQR>(a, p, s);
+        case SP_L2: return launch_space<SP_L2>(a, p, s);
+        case SP_L1: return launch_space<SP_L1>(a, p, s);
+        case SP_LINF: return launch_space<SP_LINF>(a, p, s);
+        case SP_NORMCOS: return launch_space<SP_NORMCOS>(a, p, s);
+        case SP_COSINE: return launch_space<SP_COSINE>(a, p, s);
+        case SP_ANGULAR: return launch_space<SP_ANGULAR>(a, p, s);
+        case SP_NEGDOT: return launch_space<SP_NEGDOT>(a, p, s);
+        case SP_L2SQR_SIFT: return launch_space<SP_L2SQR_SIFT>(a, p, s);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace gfxknn

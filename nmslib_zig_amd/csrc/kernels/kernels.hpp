@@ -1,0 +1,114 @@
+// Host-callable launchers of the gfx950 kernels.  Plain pointers + hipStream_t; every
+// function only enqueues work on `stream` and returns the launch status.
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace gfxknn {
+
+// Space codes (host and device).  Names: include/factory/init_spaces.h:77-86,120.
+enum SpaceCode : int {
+    SP_L2 = 0,
+    SP_L1 = 1,
+    SP_LINF = 2,
+    SP_COSINE = 3,
+    SP_ANGULAR = 4,
+    SP_NEGDOT = 5,
+    SP_L2SQR_SIFT = 6,
+    // search-time variants of the optimized HNSW index (hnsw.cc:70-102): squared L2 and
+    // cosine over pre-normalised rows
+    SP_L2SQR = 7,
+    SP_NORMCOS = 8,
+};
+
+// ---- geometry shared by host and device ------------------------------------------------
+constexpr int BF_TQ = 128;     // queries per workgroup (4 waves x 32)
+constexpr int BF_BN = 64;      // base rows staged per step
+constexpr int BF_KC = 128;     // K-chunk (floats) staged per step
+constexpr int BF_MAX_K = 512;  // largest k the selection kernels support
+
+struct BfPlan {
+    int nq, qpad, nqt;         // queries, padded to BF_TQ, number of query tiles
+    int n;                     // base rows
+    int ldb;                   // row stride (floats for f32, bytes for u8)
+    int nsplit, rows_per_split;
+    int kprime, cap;           // per-(query,split) survivors / candidate buffer capacity
+    int p2max;                 // power of two >= nsplit*kprime (rerank sort size)
+    size_t lds_select, lds_rerank;
+};
+// Fills every field of the plan from (n, dim, nq, k).  is_u8 selects the integer path.
+BfPlan bf_make_plan(int n, int dim, int nq, int k, bool is_u8);
+inline size_t bf_cand_elems(const BfPlan& p) { return (size_t)p.qpad * p.nsplit * p.cap; }
+inline size_t bf_cnt_elems(const BfPlan& p) { return (size_t)p.qpad * p.nsplit; }
+
+// Row padding for the f32 device copy: multiple of 8 floats (two 16-byte half-wave loads).
+inline int f32_row_stride(int dim) { return (dim + 7) & ~7; }
+
+// ---- preparation -------------------------------------------------------------------------
+// rowaux per space: L2 -> -0.5*||b||^2 ; COSINE/ANGULAR -> 1/||b|| (0 when ||b||^2 < 2*FLT_MIN);
+// NEGDOT -> unused (0).
+hipError_t launch_row_aux_f32(const float* base, int n, int ldb, int dim, int space, float* aux,
+                              hipStream_t s);
+// u8: aux = 256*sum(a) - sum(a^2)   (see bf_select_u8)
+hipError_t launch_row_aux_u8(const uint8_t* base, int n, int32_t* aux, hipStream_t s);
+// Copy [rows][dim] -> [rows_pad][ld] with zero fill (elem = 4 or 1 bytes).
+hipError_t launch_pad_rows(const void* src, int rows, int dim, void* dst, int rows_pad, int ld,
+                           int elem_bytes, hipStream_t s);
+// In-place L2 normalisation of rows (hnsw.cc:441-446, hnsw.h:486-497).
+hipError_t launch_normalize_rows(float* rows, int n, int ld, int dim, hipStream_t s);
+
+// ---- brute force: selection (MFMA) + exact re-rank ---------------------------------------
+hipError_t launch_bf_select_f32(const BfPlan& p, int space, const float* base, const float* aux,
+                                const float* queries_padded, unsigned long long* cand,
+                                int* cand_cnt, hipStream_t s);
+hipError_t launch_bf_select_u8(const BfPlan& p, const uint8_t* base, const int32_t* aux,
+                               const uint8_t* queries_padded, unsigned long long* cand,
+                               int* cand_cnt, hipStream_t s);
+// Direct (VALU) selection for spaces with no inner-product form (l1, linf).
+hipError_t launch_bf_select_direct_f32(const BfPlan& p, int space, const float* base,
+                                       const float* queries_padded, unsigned long long* cand,
+                                       int* cand_cnt, hipStream_t s);
+// Exact distances of the survivors in the reference's formula, (dist, position) order, top k.
+hipError_t launch_bf_rerank(const BfPlan& p, int space, int dim, int k, const void* base,
+                            const void* queries_padded, const unsigned long long* cand,
+                            const int* cand_cnt, const int32_t* ext_ids, int32_t* out_ids,
+                            float* out_dists, int32_t* out_cnt, hipStream_t s);
+
+// one pair, one wave (nmslib_get_distance)
+hipError_t launch_pair_distance(int space, const void* a, const void* b, int dim, float* out,
+                                hipStream_t s);
+
+// ---- HNSW search -------------------------------------------------------------------------
+struct HnswDeviceGraph {
+    const void* rows;          // f32 [n][ldv] or u8 [n][128]
+    const int32_t* row_norm;   // u8: sum of squares per row
+    const int32_t* links0;     // [n][maxM0+1]  (count, ids...)
+    const int64_t* up_off;     // [n] offset into up_links (ints) or -1
+    const int32_t* up_links;   // per node: level blocks of (maxM+1) ints
+    const int32_t* ext_ids;    // internal position -> external id
+    int n, dim, ldv;
+    int maxM, maxM0, maxlevel, enterpoint;
+    int space;                 // search-time SpaceCode (SP_L2SQR, SP_NORMCOS, ...)
+    int normalize_query;       // cosine on the optimized index
+};
+struct HnswSearchPlan {
+    int nq, k, ef, cap;        // cap = max(ef, k)
+    int table_size;            // LDS visited hash entries (power of two); 0 -> global bitset
+    size_t lds_bytes;
+    size_t bitset_words;       // per query, when table_size == 0
+};
+HnswSearchPlan hnsw_make_plan(const HnswDeviceGraph& g, int nq, int k, int ef, bool force_bitset);
+// queries: [nq][dim] f32 (row stride dim) or u8 [nq][128].  status[q] != 0 -> visited table
+// overflowed (caller re-runs those with the bitset variant).
+hipError_t launch_hnsw_search(const HnswDeviceGraph& g, const HnswSearchPlan& p,
+                              const void* queries, uint32_t* bitset, int32_t* out_ids,
+                              float* out_dists, int32_t* out_cnt, int32_t* out_ndc,
+                              int32_t* out_hops, int32_t* out_hops_up, int32_t* status,
+                              hipStream_t s);
+
+// ---- shard merge ---------------------------------------------------------------------------
+hipError_t launch_merge_topk(const float* dists_in, const int32_t* ids_in, int nshards, int nq,
+                             int k, float* dists_out, int32_t* ids_out, hipStream_t s);
+
+}  // namespace gfxknn

@@ -51,7 +51,8 @@ def parse_optimized_index(path):
             chunks.append(arr.ravel())
             cur += arr.size
             pos += nbytes
-    assert pos == len(raw)
+    # this repo's library appends a 32-byte trailer naming the space (ignored by the reference)
+    assert pos == len(raw) or (pos + 32 == len(raw) and raw[pos:pos + 8] == b"GFXKNNv1")
     return dict(n=n, mem_per_obj=mem_per_obj, off_level0=off_l0, off_data=off_data,
                 maxlevel=maxlevel, enterpoint=enterpoint, maxM=maxM, maxM0=maxM0,
                 dist_func=dist_func, search_method=search_method, ids=ids, datalen=datalen,

@@ -1,0 +1,160 @@
+"""-m gpu: the brute-force HIP path (MFMA selection + exact re-rank) through the C ABI, against
+(1) the committed golden vectors = outputs of the real reference, (2) the CPU oracle on seeded
+inputs, (3) size-independent properties at BASELINE sizes, (4) the reference's edge cases."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import nmslib_zig_amd as nz
+from tests import orc, refio
+from tests.gpuutil import FLOAT_SPACES, close_rel, make_index
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("D", [128, 100, 21])
+@pytest.mark.parametrize("space", FLOAT_SPACES)
+def test_golden_seq_search_float(golden, space, D):
+    base, qs = golden[f"f32_D{D}_base"], golden[f"f32_D{D}_queries"]
+    idx = make_index(space, "seq_search", base)
+    ids, ds, cnt = idx.knnQueryBatch(qs, 10)
+    assert np.all(cnt == 10)
+    np.testing.assert_array_equal(ids, golden[f"seq_{space}_D{D}_ids"])      # incl. planted ties
+    assert close_rel(ds, golden[f"seq_{space}_D{D}_dists"])                  # 1e-5 rel (north_star)
+    # single-query entry point gives the same rows (nmslib_knn_query_fill)
+    i1, d1 = idx.knnQuery(qs[3], 10)
+    np.testing.assert_array_equal(i1, ids[3])
+    np.testing.assert_array_equal(d1, ds[3])
+    # pairwise nmslib_get_distance
+    pairs, want = golden[f"pair_{space}_D{D}_idx"], golden[f"pair_{space}_D{D}_dists"]
+    got = np.array([idx.getDistance(int(a), int(b)) for a, b in pairs[:8]], np.float32)
+    assert close_rel(got, want[:8])
+    idx.close()
+
+
+def test_golden_u8_bit_exact(golden):
+    idx = make_index("l2sqr_sift", "seq_search", golden["u8_base"])
+    ids, ds, cnt = idx.knnQueryBatch(golden["u8_queries"], 100)
+    np.testing.assert_array_equal(ds, golden["seq_l2sqr_sift_dists"])        # integer distances: exact
+    np.testing.assert_array_equal(ids, golden["seq_l2sqr_sift_ids"])         # (dist, position) tie order
+    idx.close()
+
+
+@pytest.mark.parametrize("space", ["l2", "cosinesimil", "negdotprod", "angulardist", "l1", "linf"])
+def test_oracle_parity_seeded(space):
+    n, D, nq, k = 20000, 128, 200, 10
+    X, Q = refio.s_lowrank(n, D, 21), refio.s_lowrank(nq, D, 22)
+    ext = (np.arange(n, dtype=np.int32) * 7 + 3)
+    idx = make_index(space, "brute_force", X, ext)
+    ids, ds, cnt = idx.knnQueryBatch(Q, k)
+    opos, odist, _ = orc.seq_search(space, X, Q, k)
+    assert (ids == ext[opos]).mean() >= 0.999                                 # recall@k >= 0.999
+    assert close_rel(np.sort(ds, 1), np.sort(odist, 1))
+    assert np.all(np.diff(ds, axis=1) >= 0)                                   # ascending
+    idx.close()
+
+
+@pytest.mark.parametrize("D", [1, 7, 8, 129, 300, 768])
+def test_ragged_dimensions(D):
+    X, Q = refio.s_gauss(3000, D, 31), refio.s_gauss(33, D, 32)
+    idx = make_index("l2", "seq_search", X)
+    ids, ds, cnt = idx.knnQueryBatch(Q, 5)
+    opos, odist, _ = orc.seq_search("l2", X, Q, 5)
+    assert (ids == opos).mean() >= 0.999
+    assert close_rel(ds, odist)
+    idx.close()
+
+
+def test_u8_oracle_parity_with_heavy_ties():
+    rng = np.random.default_rng(5)
+    U = (rng.integers(0, 3, (30000, 128)) * 50).astype(np.uint8)             # 3-symbol alphabet: many ties
+    U[1000:1200] = U[7]
+    UQ = (rng.integers(0, 3, (70, 128)) * 50).astype(np.uint8)
+    UQ[0] = U[7]
+    idx = make_index("l2sqr_sift", "seq_search", U)
+    for k in (1, 10, 100):
+        ids, ds, cnt = idx.knnQueryBatch(UQ, k)
+        opos, odist, _ = orc.seq_search("l2sqr_sift", U, UQ, k)
+        np.testing.assert_array_equal(ds, odist)
+        np.testing.assert_array_equal(ids, opos)
+    idx.close()
+
+
+def test_edge_cases_small_and_empty():
+    X = refio.s_gauss(5, 16, 1)
+    idx = make_index("l2", "seq_search", X)
+    ids, ds, cnt = idx.knnQueryBatch(X[:2], 10)                                # k > n
+    assert cnt.tolist() == [5, 5] and ids[0, 0] == 0 and ids[1, 0] == 1
+    assert np.all(ids[:, 5:] == -1) and np.all(np.isinf(ds[:, 5:]))
+    # undersized caller buffer: size = 0 and SUCCESS (nmslib_c.cpp:307-312, golden cabi_small_buffer)
+    i4, d4 = (C.c_int32 * 2)(), (C.c_float * 2)()
+    r = nz.Result(i4, d4, 99, 2)
+    rc = nz.lib().nmslib_knn_query_fill(idx.h, X[0].ctypes.data, 16, 4, C.byref(r), 0)
+    assert (rc, r.size) == (0, 0)
+    # wrong query dimension -> QUERY_EXECUTION_FAILED (the reference CHECKs equal lengths)
+    big = np.zeros(17, np.float32)
+    r = nz.Result((C.c_int32 * 4)(), (C.c_float * 4)(), 0, 4)
+    assert nz.lib().nmslib_knn_query_fill(idx.h, big.ctypes.data, 17, 2, C.byref(r), 0) == 9
+    idx.close()
+    # one row, one query, k = 1
+    idx = make_index("cosinesimil", "seq_search", np.ones((1, 3), np.float32))
+    i, d = idx.knnQuery(np.array([1, 1, 1], np.float32), 1)
+    assert i.tolist() == [0] and abs(d[0]) < 1e-6
+    idx.close()
+    # rows added after create_index are picked up by nmslib_initialize_pool (lib.zig order)
+    idx = nz.Index("l2", "seq_search")
+    idx.buildIndex()
+    idx.addDenseBatch(X)
+    i, d = idx.knnQuery(X[4], 1)
+    assert i.tolist() == [4]
+    idx.close()
+    assert len(idx.alloc.live) == 0
+
+
+def test_large_k_and_k_limit():
+    X, Q = refio.s_gauss(2000, 32, 3), refio.s_gauss(9, 32, 4)
+    idx = make_index("l2", "seq_search", X)
+    ids, ds, cnt = idx.knnQueryBatch(Q, 512)
+    opos, odist, _ = orc.seq_search("l2", X, Q, 512)
+    assert (ids == opos).mean() >= 0.999 and close_rel(ds, odist)
+    with pytest.raises(nz.NmslibError) as e:
+        idx.knnQueryBatch(Q, 513)
+    assert e.value.code == 6                                                   # QUERY_TOO_LARGE
+    idx.close()
+
+
+def test_cosine_zero_norm_rows():
+    X = refio.s_gauss(500, 24, 8)
+    X[10] = 0
+    X[11] = 0
+    Q = refio.s_gauss(4, 24, 9)
+    idx = make_index("cosinesimil", "seq_search", X)
+    ids, ds, cnt = idx.knnQueryBatch(Q, 500)
+    opos, odist, _ = orc.seq_search("cosinesimil", X, Q, 500)
+    assert close_rel(ds, odist)
+    for q in range(4):
+        assert ds[q][list(ids[q]).index(10)] == 1.0                           # distcomp_scalar.cc:154-160
+    idx.close()
+
+
+def test_full_size_properties_1M():
+    """BASELINE config 2 size (1M x 128, Q=1024, k=10): properties that need no CPU scan."""
+    n, D, nq, k = 1_000_000, 128, 1024, 10
+    X = refio.s_lowrank(n, D, 42)
+    Q = X[::977][:nq].copy()                        # queries ARE base rows: rank 0 must be themselves
+    idx = make_index("l2", "seq_search", X)
+    ids, ds, cnt = idx.knnQueryBatch(Q, k)
+    assert np.all(cnt == k)
+    np.testing.assert_array_equal(ids[:, 0], np.arange(nq) * 977)
+    assert np.all(ds[:, 0] == 0) and np.all(np.diff(ds, axis=1) >= 0)
+    assert all(len(set(r)) == k for r in ids.tolist())
+    # spot-check 16 queries against the oracle's full scan
+    sel = np.arange(0, nq, 64)
+    opos, odist, _ = orc.seq_search("l2", X, Q[sel], k)
+    assert (ids[sel] == opos).mean() >= 0.999 and close_rel(ds[sel], odist)
+    # distances are reproducible through nmslib_get_distance (same formula, same device)
+    for q in (0, 511):
+        for j in (1, 9):
+            assert abs(idx.getDistance(int(q * 977), int(ids[q, j])) - ds[q, j]) <= 1e-5 * ds[q, j]
+    idx.close()

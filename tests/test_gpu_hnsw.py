@@ -1,0 +1,129 @@
+"""-m gpu: the HNSW search kernel through the C ABI.  Same-graph parity: graphs come either from
+the reference's own saved index file (golden) or from this library's deterministic single-thread
+build (which test_cabi_cpu.py proves equal to the reference's), so GPU results must match the
+reference's SearchV1Merge item for item; floats within 1e-5 relative."""
+import numpy as np
+import pytest
+
+import nmslib_zig_amd as nz
+from tests import orc, refio
+from tests.gpuutil import close_rel, ids_match_modulo_ties, make_index
+
+pytestmark = pytest.mark.gpu
+
+
+def test_search_reference_built_index_file(golden, tmp_path):
+    p = str(tmp_path / "ref.idx")
+    golden["hnsw_l2_index_file"].tofile(p)
+    idx = nz.Index.load(p, load_data=False)
+    qs = golden["f32_D128_queries"]
+    for ef in (5, 20, 200):
+        idx.setQueryTimeParams(efSearch=ef)
+        ids, ds, cnt = idx.knnQueryBatch(qs, 10)
+        want_i, want_d = golden[f"hnsw_l2_ef{ef}_v1merge_ids"], golden[f"hnsw_l2_ef{ef}_v1merge_dists"]
+        valid = want_i >= 0
+        np.testing.assert_array_equal(ids[valid], want_i[valid])
+        assert close_rel(ds[valid], want_d[valid])
+        np.testing.assert_array_equal(cnt, valid.sum(1))
+    idx.close()
+
+
+@pytest.mark.parametrize("space,D", [("l2", 128), ("cosinesimil", 100), ("negdotprod", 21), ("l1", 21)])
+def test_golden_build_then_search(golden, space, D):
+    idx = make_index(space, "hnsw", golden[f"f32_D{D}_base"], M=8, efConstruction=50, indexThreadQty=1)
+    qs = golden[f"f32_D{D}_queries"]
+    for ef in (5, 20, 200):
+        idx.setQueryTimeParams(efSearch=ef)
+        ids, ds, cnt = idx.knnQueryBatch(qs, 10)
+        want_i, want_d = golden[f"hnsw_{space}_ef{ef}_v1merge_ids"], golden[f"hnsw_{space}_ef{ef}_v1merge_dists"]
+        valid = want_i >= 0
+        assert close_rel(ds[valid], want_d[valid])
+        assert ids_match_modulo_ties(ids, ds, want_i, want_d) or (ids[valid] == want_i[valid]).mean() >= 0.999
+    idx.close()
+
+
+def test_cabi_default_ef_is_the_shims_200_and_l2_is_squared(golden):
+    ext = golden["cabi_ids_in"]
+    idx = make_index("l2", "hnsw", golden["f32_D128_base"], ext, M=8, efConstruction=50, indexThreadQty=1)
+    ids, ds, cnt = idx.knnQueryBatch(golden["f32_D128_queries"], 10)
+    np.testing.assert_array_equal(ids, golden["cabi_hnsw_l2_ids"])            # external ids, efSearch=200
+    assert close_rel(ds, golden["cabi_hnsw_l2_dists"])                        # squared L2
+    # ... while nmslib_get_distance stays sqrt (nmslib_c.cpp:1166): both quirks kept
+    d01 = idx.getDistance(0, 1)
+    assert abs(d01 - orc.space_distance("l2", golden["f32_D128_base"][0], golden["f32_D128_base"][1])) < 1e-4
+    idx.close()
+
+
+def test_generic_path_angular_and_u8(golden):
+    idx = make_index("angulardist", "hnsw", golden["f32_D21_base"], M=8, efConstruction=50, indexThreadQty=1)
+    idx.setQueryTimeParams(efSearch=20)
+    ids, ds, cnt = idx.knnQueryBatch(golden["f32_D21_queries"], 10)
+    assert close_rel(ds, golden["hnsw_angulardist_dists"], rtol=1e-4, atol=1e-5)   # acos amplifies ulps near 0
+    assert (ids == golden["hnsw_angulardist_ids"]).mean() >= 0.99
+    idx.close()
+    idx = make_index("l2sqr_sift", "hnsw", golden["u8_base"], M=8, efConstruction=50, indexThreadQty=1)
+    idx.setQueryTimeParams(efSearch=150)
+    ids, ds, cnt = idx.knnQueryBatch(golden["u8_queries"], 100)
+    np.testing.assert_array_equal(ds, golden["hnsw_l2sqr_sift_dists"])        # integer distances: exact
+    assert ids_match_modulo_ties(ids, ds, golden["hnsw_l2sqr_sift_ids"], golden["hnsw_l2sqr_sift_dists"])
+    idx.close()
+
+
+@pytest.mark.parametrize("space", ["l2", "cosinesimil", "negdotprod"])
+def test_oracle_parity_same_graph_with_counters(space):
+    """20k rows, M=16: ids, distances AND the work counters (distance computations, expansions)
+    equal the oracle's on the same graph -- the kernel walks the same path."""
+    import torch
+    n, D, nq = 20000, 128, 256
+    X, Q = refio.s_lowrank(n, D, 51), refio.s_lowrank(nq, D, 52)
+    idx = make_index(space, "hnsw", X, M=16, efConstruction=100, indexThreadQty=1)
+    g = orc.HnswGraph.build(space, X, 16, 100)
+    for ef, k in ((32, 10), (128, 10), (200, 100)):
+        idx.setQueryTimeParams(efSearch=ef)
+        dq = torch.from_numpy(Q).cuda()
+        d_ids = torch.empty((nq, k), dtype=torch.int32, device="cuda")
+        d_ds = torch.empty((nq, k), dtype=torch.float32, device="cuda")
+        d_cnt = torch.empty((nq,), dtype=torch.int32, device="cuda")
+        idx.knn_device(dq.data_ptr(), nq, D, k, d_ids.data_ptr(), d_ds.data_ptr(), d_cnt.data_ptr(),
+                       torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        opos, odist, ocnt, ondc, ohops = g.search(Q, k, ef)
+        ids, ds = d_ids.cpu().numpy(), d_ds.cpu().numpy()
+        assert (ids == opos).mean() >= 0.999
+        assert close_rel(ds, odist)
+        ndc, hops, hops_up = (x.astype(np.int64) for x in idx.read_counters(nq))
+        assert np.mean(ndc == ondc) >= 0.98 and abs(ndc.mean() / ondc.mean() - 1) < 0.01
+        assert np.mean(hops == ohops) >= 0.98
+    idx.close()
+
+
+def test_visited_table_overflow_falls_back_to_bitset_not_cpu():
+    """A tiny graph degree with a huge ef fills the LDS hash: the engine re-runs on the HBM bitset
+    variant of the same kernel; results still equal the oracle."""
+    n, D, nq = 30000, 32, 40
+    X, Q = refio.s_gauss(n, D, 61), refio.s_gauss(nq, D, 62)
+    idx = make_index("l2", "hnsw", X, M=6, efConstruction=40, indexThreadQty=1)
+    g = orc.HnswGraph.build("l2", X, 6, 40)
+    for ef in (700, 1000):
+        idx.setQueryTimeParams(efSearch=ef, algoType="v1merge")
+        ids, ds, cnt = idx.knnQueryBatch(Q, 10)
+        opos, odist, _, _, _ = g.search(Q, 10, ef)
+        assert (ids == opos).mean() >= 0.999 and close_rel(ds, odist)
+    idx.close()
+
+
+def test_multithreaded_build_recall_200k():
+    """Default (all-thread) build at 200k rows: recall@10 against exact GPU brute force, NMSLIB's
+    recall definition (eval_results.h:122-130)."""
+    n, D, nq, k = 200_000, 128, 512, 10
+    X, Q = refio.s_lowrank(n, D, 42), refio.s_lowrank(nq, D, 43)
+    bf = make_index("l2", "seq_search", X)
+    gt_i, gt_d, _ = bf.knnQueryBatch(Q, 32)
+    bf.close()
+    idx = make_index("l2", "hnsw", X, M=16, efConstruction=200)
+    idx.setQueryTimeParams(efSearch=128)
+    ids, ds, cnt = idx.knnQueryBatch(Q, k)
+    rec = refio.recall_nmslib(ids, gt_i, gt_d ** 2, k)
+    assert rec >= 0.97, rec                      # the reference reaches 0.976 at 200k / ef=200
+    assert np.all(np.diff(ds, axis=1) >= 0)
+    idx.close()
