@@ -56,6 +56,13 @@ nmslib_error_t nmslib_gpu_merge_topk(const float* d_dists_in, const int32_t* d_i
                                      size_t nshards, size_t query_count, size_t k,
                                      float* d_dists_out, int32_t* d_ids_out, void* stream);
 
+/* Live timing of the dominant kernel (bf_select_* for brute force, hnsw_search for HNSW) with
+ * HIP events recorded on the stream the kernel is launched on.  enable != 0 starts recording
+ * (one event pair per batch); a call with total_ms / launches non-NULL waits for the recorded
+ * events, returns their summed duration and launch count, and clears the record. */
+nmslib_error_t nmslib_gpu_kernel_timing(nmslib_index_handle_t index, int enable, double* total_ms,
+                                        uint64_t* launches);
+
 /* Engine statistics of the last finalize/build (host values). */
 typedef struct {
     double upload_seconds;   /* host -> HBM copy of the rows            */

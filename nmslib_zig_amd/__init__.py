@@ -74,6 +74,15 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise ImportError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                           "or `make -C nmslib_zig_amd/csrc` (the engine has no CPU fallback)")
+    # One HIP runtime per process: PyTorch's wheels request "libamdhip64.so" (their bundled copy)
+    # while this library is linked against the SONAME "libamdhip64.so.7".  Opening the runtime
+    # by its unversioned NAME first makes both requests resolve to the same loaded object,
+    # whichever of torch / this library is imported first (two runtimes in one process cannot
+    # both see the GPU).
+    try:
+        C.CDLL("libamdhip64.so", mode=C.RTLD_GLOBAL)
+    except OSError:
+        pass
     L = C.CDLL(LIB_PATH)
     vp, sz, i32p, f32p = C.c_void_p, C.c_size_t, C.POINTER(C.c_int32), C.POINTER(C.c_float)
     AP = C.POINTER(Allocator)
@@ -122,6 +131,7 @@ def lib():
         "nmslib_gpu_last_batch_counters": (C.c_int, [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]),
         "nmslib_gpu_merge_topk": (C.c_int, [vp, vp, sz, sz, sz, vp, vp, vp]),
         "nmslib_gpu_get_stats": (C.c_int, [vp, C.POINTER(GpuStats)]),
+        "nmslib_gpu_kernel_timing": (C.c_int, [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(L, name)   # AttributeError here = a declared symbol is not exported
@@ -147,7 +157,7 @@ ABI_SYMBOLS_C = [  # the 37 symbols of the reference boundary
 ]
 ABI_SYMBOLS_GPU = ["nmslib_gpu_device_count", "nmslib_gpu_finalize",
                    "nmslib_gpu_knn_query_batch_device", "nmslib_gpu_last_batch_counters",
-                   "nmslib_gpu_merge_topk", "nmslib_gpu_get_stats"]
+                   "nmslib_gpu_merge_topk", "nmslib_gpu_get_stats", "nmslib_gpu_kernel_timing"]
 
 
 class TrackingAllocator:
@@ -342,6 +352,13 @@ class Index:
                 raise RuntimeError(f"hipMemcpy failed: {rc}")
             out.append(a)
         return tuple(out)
+
+    def kernel_timing(self, enable=True, collect=False):
+        """HIP-event timing of the dominant kernel: -> (total_ms, launches) when collect."""
+        ms, n = C.c_double(), C.c_uint64()
+        _check(lib().nmslib_gpu_kernel_timing(self.h, int(enable), C.byref(ms) if collect else None,
+                                              C.byref(n) if collect else None), self.alloc)
+        return (ms.value, n.value) if collect else None
 
     def stats(self):
         s = GpuStats()

@@ -656,6 +656,17 @@ nmslib_error_t nmslib_gpu_merge_topk(const float* d_dists_in, const int32_t* d_i
     });
 }
 
+nmslib_error_t nmslib_gpu_kernel_timing(nmslib_index_handle_t handle, int enable, double* total_ms,
+                                        uint64_t* launches) {
+    if (!handle) FAIL(NMSLIB_ERROR_INVALID_ARGUMENT, "Invalid index");
+    return guarded(NMSLIB_ERROR_RUNTIME, "kernel_timing", [&] {
+        Engine* e = H(handle)->engine;
+        std::lock_guard<std::mutex> lk(e->mu);
+        if (total_ms || launches) e->collect_profile(total_ms, launches);
+        e->set_profiling(enable != 0);
+    });
+}
+
 nmslib_error_t nmslib_gpu_get_stats(nmslib_index_handle_t handle, nmslib_gpu_stats_t* out) {
     if (!handle || !out) FAIL(NMSLIB_ERROR_INVALID_ARGUMENT, "Invalid arguments");
     Engine* e = H(handle)->engine;

@@ -131,7 +131,40 @@ Engine::Engine(const std::string& space, const std::string& method, int data_typ
 }
 
 Engine::~Engine() {
+    for (auto& pr : prof_events_) {
+        (void)hipEventDestroy(pr.first);
+        (void)hipEventDestroy(pr.second);
+    }
     if (stream_) (void)hipStreamDestroy(stream_);
+}
+
+void Engine::prof_begin(hipStream_t s) {
+    if (!prof_ || prof_events_.size() >= 65536) return;
+    hipEvent_t a, b;
+    hip_check(hipEventCreate(&a), "hipEventCreate");
+    hip_check(hipEventCreate(&b), "hipEventCreate");
+    prof_events_.emplace_back(a, b);
+    hip_check(hipEventRecord(a, s), "hipEventRecord");
+}
+void Engine::prof_end(hipStream_t s) {
+    if (!prof_ || prof_events_.empty()) return;
+    hip_check(hipEventRecord(prof_events_.back().second, s), "hipEventRecord");
+}
+void Engine::collect_profile(double* total_ms, uint64_t* launches) {
+    double tot = 0;
+    uint64_t n = 0;
+    for (auto& pr : prof_events_) {
+        float ms = 0;
+        if (hipEventSynchronize(pr.second) == hipSuccess && hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) {
+            tot += ms;
+            ++n;
+        }
+        (void)hipEventDestroy(pr.first);
+        (void)hipEventDestroy(pr.second);
+    }
+    prof_events_.clear();
+    if (total_ms) *total_ms = tot;
+    if (launches) *launches = n;
 }
 
 void Engine::add_row(const void* data, size_t elem_count, int32_t id) {
@@ -445,6 +478,7 @@ void Engine::knn_brute(const void* d_queries, size_t nq, size_t k, int32_t* d_id
     ws_cand_.ensure(bf_cand_elems(p) * 8);
     ws_cnt_.ensure(bf_cnt_elems(p) * 4);
     hip_check(launch_pad_rows(d_queries, (int)nq, dim_eff, ws_qpad_.ptr(), p.qpad, p.ldb, elem, stream), "pad queries");
+    prof_begin(stream);
     if (is_u8()) {
         hip_check(launch_bf_select_u8(p, d_rows_.as<uint8_t>(), d_aux_.as<int32_t>(), ws_qpad_.as<uint8_t>(),
                                       ws_cand_.as<unsigned long long>(), ws_cnt_.as<int>(), stream),
@@ -458,6 +492,7 @@ void Engine::knn_brute(const void* d_queries, size_t nq, size_t k, int32_t* d_id
                                        ws_cand_.as<unsigned long long>(), ws_cnt_.as<int>(), stream),
                   "bf_select_f32");
     }
+    prof_end(stream);
     hip_check(launch_bf_rerank(p, space_, dim_eff, (int)k, d_rows_.ptr(), ws_qpad_.ptr(),
                                ws_cand_.as<unsigned long long>(), ws_cnt_.as<int>(), d_ids_.as<int32_t>(), d_ids,
                                d_dists, d_cnt, stream),
@@ -486,9 +521,11 @@ void Engine::knn_hnsw(const void* d_queries, size_t nq, size_t k, int32_t* d_ids
         hip_check(hipMemsetAsync(ws_bitset_.ptr(), 0, nq * p.bitset_words * 4, stream), "clear visited bitset");
         bitset = ws_bitset_.as<uint32_t>();
     }
+    prof_begin(stream);
     hip_check(launch_hnsw_search(dg_, p, d_queries, bitset, d_ids, d_dists, cnt, ws_ndc_.as<int32_t>(),
                                  ws_hops_.as<int32_t>(), ws_hops_up_.as<int32_t>(), ws_status_.as<int32_t>(), stream),
               "hnsw_search");
+    prof_end(stream);
     have_counters_ = true;
     if (p.table_size != 0) {
         // the LDS visited table is exact but finite: queries that filled it report status 1

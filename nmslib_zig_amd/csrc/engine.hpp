@@ -151,6 +151,10 @@ class Engine {
     const int32_t* last_hops() const { return have_counters_ ? ws_hops_.as<int32_t>() : nullptr; }
     const int32_t* last_hops_up() const { return have_counters_ ? ws_hops_up_.as<int32_t>() : nullptr; }
 
+    // HIP-event timing of the dominant kernel (nmslib_gpu_kernel_timing)
+    void set_profiling(bool on) { prof_ = on; }
+    void collect_profile(double* total_ms, uint64_t* launches);
+
     double upload_seconds = 0, build_seconds = 0;
     size_t hbm_bytes() const;
 
@@ -198,6 +202,10 @@ class Engine {
     DevBuf ws_q_, ws_qpad_, ws_cand_, ws_cnt_, ws_ids_, ws_dists_, ws_outcnt_, ws_status_, ws_bitset_;
     DevBuf ws_ndc_, ws_hops_, ws_hops_up_, ws_pair_;
     bool have_counters_ = false;
+    bool prof_ = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events_;
+    void prof_begin(hipStream_t s);
+    void prof_end(hipStream_t s);
 };
 
 }  // namespace gfxknn
