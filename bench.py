@@ -59,18 +59,30 @@ def make_data(a):
     return refio.s_lowrank(a.n, a.dim, 42), refio.s_lowrank(a.batch, a.dim, 43)
 
 
+def host_threads():
+    """Hardware threads this process may actually use: affinity mask, capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
 def cpu_baseline(a, X, Q, gt_ids, gt_d):
     """The reference's own code (oracle/_ref/ref_driver) on this host, all hardware threads,
     query q on thread q mod T (Experiments::Execute protocol).  Bounded sample."""
     from tests import orc
-    cores = os.cpu_count() or 1
+    cores = host_threads()
     space = "l2sqr_sift" if a.workload == "sift" else "l2"
     if a.workload == "hnsw":
         method, ip, qp = "hnsw", f"M=16,efConstruction=200,indexThreadQty={cores}", f"efSearch={a.ef}"
         ns = a.cpu_sample or min(Q.shape[0], 1024)
     else:
         method, ip, qp = "seq_search", "", ""
-        ns = a.cpu_sample or min(Q.shape[0], 16 * cores)      # ~0.08 s per query per thread at 1M
+        ns = a.cpu_sample or min(Q.shape[0], max(64, 32 * cores))  # ~20-30 s of CPU work at 1M rows
     Qs = Q[:ns]
     t0 = time.time()
     if refio.HAVE_REF:
@@ -86,8 +98,9 @@ def cpu_baseline(a, X, Q, gt_ids, gt_d):
         kind, qps, used, extra = "port", ns / (time.time() - t1), 1, {}
     rec = None
     if gt_ids is not None:
-        gd = gt_d[:ns] ** 2 if (a.workload == "hnsw") else gt_d[:ns]
-        rec = refio.recall_nmslib(ids, gt_ids[:ns], gd, a.k, integer=(a.workload == "sift"))
+        m = min(ns, len(gt_ids))
+        gd = gt_d[:m] ** 2 if (a.workload == "hnsw") else gt_d[:m]
+        rec = refio.recall_nmslib(ids[:m], gt_ids[:m], gd, a.k, integer=(a.workload == "sift"))
     out = {"value": round(float(qps), 2), "unit": "queries/s", "cores": used, "kind": kind,
            "sample": f"{ns} of the {Q.shape[0]} queries against all {X.shape[0]} rows, method={method}"
                      + (f", {qp}" if qp else "") + f", {used} threads",

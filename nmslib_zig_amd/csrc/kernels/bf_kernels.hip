@@ -18,6 +18,8 @@
 // that query is a lane-local register and the epilogue is one compare per element.
 // Survivors are appended to a per-(query, split) buffer in HBM (L2-resident); when a buffer
 // nears capacity the owning wave sorts it in LDS, keeps k', and raises the threshold.
+#include <cstdlib>
+
 #include "common.cuh"
 #include "kernels.hpp"
 
@@ -34,28 +36,138 @@ struct BfArgs {
     int n, ldb, nqt, nsplit, rows_per_split, kprime, cap;
     int kcs;      // floats staged per K-chunk = min(ldb, 128)
     int nchunks;  // ceil(ldb / 128)
+    int dbg;      // NMSLIB_GPU_DEBUG bits (timing experiments only): 1 skip epilogue, 2 skip staging, 4 no stagger, 8 no barrier
 };
 
 // row handled by accumulator register r of a lane in half h (C/D map of the 32x32 MFMAs)
 __device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
-// Sort the survivors of one query (wave-cooperative), keep k', return the new threshold as an
-// order-preserving uint32 (0 when fewer than k' survive).
-__device__ __forceinline__ uint32_t compact_candidates(u64* g, int n, int kprime, u64* scratch,
-                                                       int lane, int* cnt_slot) {
-    int P = next_pow2(n < 2 ? 2 : n);
-    for (int i = lane; i < P; i += 64) scratch[i] = (i < n) ? g[i] : 0ull;
+// Candidate buffer of one (query, split): `cap` keys, split into two halves of cap/2.  The two
+// lanes that own a query (l and l+32) append to their own half with a private register counter:
+// no atomics and no cross-lane traffic on the append path.
+//
+// Compaction (wave-cooperative, rare): gather n0 keys of half 0 and n1 keys of half 1, keep the
+// k' largest in half 0 (sorted, best first), return the new threshold as an order-preserving
+// uint32 (0 when fewer than k' keys exist).
+__device__ __forceinline__ u64 wave_max_u64(u64 v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const u64 other = __shfl_xor(v, o, 64);
+        v = other > v ? other : v;
+    }
+    return v;
+}
+
+__device__ __forceinline__ u64 gather_key(const u64* g, int idx, int n0, int n1, int half) {
+    if (idx < n0) return g[idx];
+    if (idx - n0 < n1) return g[half + idx - n0];
+    return 0ull;
+}
+
+// n0 + n1 <= 256 and k' <= 32: four keys per lane in registers, k' rounds of (lane max, wave
+// max, retire the winner).  Keys are unique (they embed the position): one retires per round.
+__device__ __forceinline__ uint32_t compact_small(u64* g, int n0, int n1, int half, int kprime, int lane,
+                                                  int* keep_out) {
+    const int n = n0 + n1;
+    u64 r0 = gather_key(g, lane, n0, n1, half);
+    u64 r1 = gather_key(g, lane + 64, n0, n1, half);
+    u64 r2 = gather_key(g, lane + 128, n0, n1, half);
+    u64 r3 = gather_key(g, lane + 192, n0, n1, half);
+    const int keep = n < kprime ? n : kprime;
+    u64 mine = 0ull;
+    for (int t = 0; t < keep; ++t) {
+        const u64 a01 = r0 > r1 ? r0 : r1, a23 = r2 > r3 ? r2 : r3;
+        const u64 w = wave_max_u64(a01 > a23 ? a01 : a23);
+        r0 = r0 == w ? 0ull : r0;
+        r1 = r1 == w ? 0ull : r1;
+        r2 = r2 == w ? 0ull : r2;
+        r3 = r3 == w ? 0ull : r3;
+        if (lane == t) mine = w;
+    }
+    if (lane < keep) g[lane] = mine;
+    const u64 kth = __shfl(mine, kprime - 1, 64);
+    *keep_out = keep;
+    return n >= kprime ? (uint32_t)(kth >> 32) : 0u;
+}
+
+// general case: bitonic sort of the gathered keys in this wave's LDS scratch
+__device__ __forceinline__ uint32_t compact_sort(u64* g, int n0, int n1, int half, int kprime, u64* scratch,
+                                                 int lane, int* keep_out) {
+    const int n = n0 + n1;
+    const int P = next_pow2(n < 2 ? 2 : n);
+    for (int i = lane; i < P; i += 64) scratch[i] = gather_key(g, i, n0, n1, half);
     __builtin_amdgcn_wave_barrier();
     wave_bitonic_u64(scratch, P, lane, /*descending=*/true);
-    int keep = n < kprime ? n : kprime;
+    const int keep = n < kprime ? n : kprime;
     for (int i = lane; i < keep; i += 64) g[i] = scratch[i];
-    uint32_t thr = (n >= kprime) ? (uint32_t)(scratch[kprime - 1] >> 32) : 0u;
-    if (lane == 0) *cnt_slot = keep;
+    const uint32_t thr = (n >= kprime) ? (uint32_t)(scratch[kprime - 1] >> 32) : 0u;
+    *keep_out = keep;
     __builtin_amdgcn_wave_barrier();
     return thr;
 }
 
-template <int MODE>
+__device__ __forceinline__ bool need_pair(bool need) {  // either lane of the query asks
+    const u64 m = __ballot(need);
+    const int lane = threadIdx.x & 63;
+    return ((m | (m >> 32) | (m << 32)) >> lane) & 1ull;
+}
+
+// Compact every query whose lanes ask for it (need), update the per-lane counters (mycnt) and
+// return, per lane, the new threshold of ITS query as ord bits (0 = unchanged).
+__device__ __forceinline__ uint32_t compact_queries(u64* gbase /* query 0 of this wave */, size_t qstride, int cap,
+                                                    int kprime, u64* scratch, bool need, int& mycnt, int lane) {
+    const int half = cap >> 1, l31 = lane & 31;
+    if (__any(need)) {
+        // cheap case, all queries at once: the two halves together hold no more than k' keys ->
+        // the upper lane appends its keys behind the lower lane's, nothing is dropped
+        const int n_other = __shfl_xor(mycnt, 32, 64);
+        const bool fits = need_pair(need) && (mycnt + n_other <= kprime);
+        if (fits) {
+            if (lane >= 32) {
+                u64* g = gbase + (size_t)l31 * qstride;
+                for (int i = 0; i < mycnt; ++i) g[n_other + i] = g[half + i];
+                mycnt = 0;
+            } else {
+                mycnt += n_other;
+            }
+            need = false;
+        }
+    }
+    u64 m = __ballot(need);
+    m = (m | (m >> 32)) & 0xFFFFFFFFull;  // either lane of a query may ask
+    uint32_t my_thr = 0u;
+    if (m) {
+        // this wave's own appended keys must be visible to its loads below
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+    while (m) {
+        const int q = __ffsll((long long)m) - 1;
+        m &= m - 1;
+        const int n0 = __shfl(mycnt, q, 64), n1 = __shfl(mycnt, q + 32, 64);
+        u64* g = gbase + (size_t)q * qstride;
+        int keep;
+        uint32_t t;
+        if (cap <= 256 && kprime <= 32) t = compact_small(g, n0, n1, half, kprime, lane, &keep);
+        else t = compact_sort(g, n0, n1, half, kprime, scratch, lane, &keep);
+        if (l31 == q) {
+            mycnt = (lane < 32) ? keep : 0;
+            my_thr = t;
+        }
+    }
+    return my_thr;
+}
+
+// FULL: every staged K-chunk holds exactly 128 floats (ldb % 128 == 0): the MFMA loop is
+// branch-free.  ONE: the whole row is one chunk (ldb == 128): the query fragments are loaded
+// once, outside the row loop.
+//
+// Software pipeline inside ONE wave (MFMA modes): the scores of stage s stay in one accumulator
+// set while the MFMAs of stage s+1 fill the other; the selection epilogue of stage s (compare,
+// rare append) is issued between those MFMAs, two elements per 8-MFMA group.  A 32x32x2 f32
+// MFMA keeps the matrix pipe busy for 64 cycles but the issue port for only a few, so the
+// epilogue's VALU/SALU work rides in the MFMA shadow instead of idling the pipe.
+template <int MODE, bool FULL, bool ONE>
 __global__ __launch_bounds__(256, 2) void bf_select_f32_kernel(BfArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -70,35 +182,49 @@ __global__ __launch_bounds__(256, 2) void bf_select_f32_kernel(BfArgs a) {
     const int split = (rest / a.nqt) * 8 + xcd;
     if (split >= a.nsplit) return;
 
-    const int kcs = a.kcs;
+    constexpr bool kDirect = (MODE == BF_L1 || MODE == BF_LINF);
+    constexpr bool kDelay = !kDirect;  // epilogue of stage s overlapped with the MFMAs of s+1
+    constexpr bool kAux = (MODE == BF_L2 || MODE == BF_COS);
+
+    const int kcs = FULL ? BF_KC : a.kcs;
     const int lds_stride = kcs + 4;  // +16 B pad: conflict-free ds_read_b128 of 32 rows
     float* tile = reinterpret_cast<float*>(smem);                      // [2][BN][lds_stride]
-    float* auxs = tile + 2 * BF_BN * lds_stride;                       // [2][BN]
-    int* cnt = reinterpret_cast<int*>(auxs + 2 * BF_BN);               // [TQ]
-    u64* scratch_all = reinterpret_cast<u64*>(cnt + BF_TQ);            // [4][cap]
-    u64* scratch = scratch_all + (size_t)wave * a.cap;
-
-    if (tid < BF_TQ) cnt[tid] = 0;
+    float* auxs = tile + 2 * BF_BN * lds_stride;                       // [4][BN], 3 in rotation
+    u64* scratch = reinterpret_cast<u64*>(auxs + 4 * BF_BN) + (size_t)wave * a.cap;  // [4][cap]
 
     const int qidx = qt * BF_TQ + wave * 32 + l31;  // this lane's query (row of the padded batch)
-    u64* candq = a.cand + ((size_t)qidx * a.nsplit + split) * a.cap;
-    int* my_cnt = &cnt[wave * 32 + l31];
+    const int half = a.cap >> 1;
+    // this lane's half of its query's candidate buffer, and its private fill counter
+    u64* candq = a.cand + ((size_t)qidx * a.nsplit + split) * a.cap + (size_t)h * half;
+    int mycnt = 0;
+    u64* wave_cand = a.cand + ((size_t)(qt * BF_TQ + wave * 32) * a.nsplit + split) * a.cap;  // query 0 of this wave
+    const size_t qstride = (size_t)a.nsplit * a.cap;
+    // Small k' (<= 16): each lane also keeps the 8 best scores IT has seen, sorted, in
+    // registers.  The 16 values held by the two lanes of a query are all >= min(their 8th
+    // bests), so that minimum never exceeds the query's k'-th best score: a threshold that
+    // tightens continuously with no memory traffic and no compaction.
+    const bool use_top8 = a.kprime <= 16;
+    float t8[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t8[i] = -INFINITY;
+    float thr = -INFINITY;  // lane-local threshold of this lane's query
 
     const int r_begin = split * a.rows_per_split;
     const int r_end = min(a.n, r_begin + a.rows_per_split);
     const int nstages = r_end > r_begin ? (r_end - r_begin + BF_BN - 1) / BF_BN : 0;
-    const int nsteps = nstages * a.nchunks;
+    const int nchunks = ONE ? 1 : a.nchunks;
+    const int nsteps = nstages * nchunks;
 
     // staging map: 32 threads per row (16 B each), 8 rows per pass, 8 passes = 64 rows
     const int sc = tid & 31, sr = tid >> 5;
     f32x4 stg[8];
     float stg_aux = 0.f;
 
-    auto issue_loads = [&](int step) {
-        const int stage = step / a.nchunks, kc = step - stage * a.nchunks;
+    auto issue_loads = [&](int step) __attribute__((always_inline)) {
+        const int stage = step / nchunks, kc = step - stage * nchunks;
         const int row0 = r_begin + stage * BF_BN;
         const int col0 = kc * BF_KC + sc * 4;
-        const int kc_len = min(kcs, a.ldb - kc * BF_KC);
+        const int kc_len = FULL ? BF_KC : min(kcs, a.ldb - kc * BF_KC);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int row = row0 + sr + 8 * i;
@@ -107,28 +233,31 @@ __global__ __launch_bounds__(256, 2) void bf_select_f32_kernel(BfArgs a) {
                 v = *reinterpret_cast<const f32x4*>(a.base + (size_t)row * a.ldb + col0);
             stg[i] = v;
         }
-        if (kc == 0 && MODE != BF_DOT && MODE != BF_L1 && MODE != BF_LINF && tid < BF_BN) {
+        if (kAux && kc == 0 && tid < BF_BN) {
+            // rows past the end of the split get -inf: L2 score = dot + (-inf), cosine score =
+            // 0 * (-inf) = NaN -- neither can pass "s > thr", so those modes need no position test
             const int row = row0 + tid;
-            stg_aux = row < r_end ? a.aux[row] : 0.f;
+            stg_aux = row < r_end ? a.aux[row] : -INFINITY;
         }
     };
-    auto write_lds = [&](int step) {
-        const int stage = step / a.nchunks, kc = step - stage * a.nchunks;
+    auto write_lds = [&](int step) __attribute__((always_inline)) {
+        const int stage = step / nchunks, kc = step - stage * nchunks;
         float* t = tile + (step & 1) * BF_BN * lds_stride;
         if (sc * 4 < kcs) {
 #pragma unroll
             for (int i = 0; i < 8; ++i)
                 *reinterpret_cast<f32x4*>(t + (sr + 8 * i) * lds_stride + sc * 4) = stg[i];
         }
-        if (kc == 0 && MODE != BF_DOT && MODE != BF_L1 && MODE != BF_LINF && tid < BF_BN)
-            auxs[(stage & 1) * BF_BN + tid] = stg_aux;
+        // aux rotates over three buffers: the delayed epilogue of stage s still reads buffer
+        // s % 3 while stage s+2's values are being written
+        if (kAux && kc == 0 && tid < BF_BN) auxs[(stage % 3) * BF_BN + tid] = stg_aux;
     };
 
     // query fragments: lane (l31, h) holds dims 8t + 4h + {0..3} of its query, t = 0..15
     f32x4 bq[16];
-    auto load_queries = [&](int kc) {
+    auto load_queries = [&](int kc) __attribute__((always_inline)) {
         const float* qrow = a.queries + (size_t)qidx * a.ldb + kc * BF_KC + 4 * h;
-        const int kc_len = min(kcs, a.ldb - kc * BF_KC);
+        const int kc_len = FULL ? BF_KC : min(kcs, a.ldb - kc * BF_KC);
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -136,13 +265,10 @@ __global__ __launch_bounds__(256, 2) void bf_select_f32_kernel(BfArgs a) {
             bq[t] = v;
         }
     };
-
-    constexpr bool kDirect = (MODE == BF_L1 || MODE == BF_LINF);
-    f32x16 acc0, acc1;  // scores of the two 32-row blocks in the MFMA C/D layout
     // direct (VALU) modes: every lane needs ALL dims of its query; the other half comes from
     // the partner lane (l ^ 32) once per K-chunk.  qlo/qhi = dims 8t+{0..3} / 8t+{4..7}.
     f32x4 qlo[kDirect ? 16 : 1], qhi[kDirect ? 16 : 1];
-    auto spread_queries = [&]() {
+    auto spread_queries = [&]() __attribute__((always_inline)) {
         if constexpr (kDirect) {
 #pragma unroll
             for (int t = 0; t < 16; ++t) {
@@ -155,136 +281,239 @@ __global__ __launch_bounds__(256, 2) void bf_select_f32_kernel(BfArgs a) {
         }
     };
 
-    float thr = -INFINITY;      // lane-local threshold of this lane's query
+    // Appended keys wait in four registers and are stored right AFTER the staging wait of the
+    // stage (flush_pending): vmcnt counts stores and loads together and in order, so a store
+    // issued between the tile prefetch and its vmcnt wait would put its whole latency on the
+    // critical path of every stage.
+    u64 pend0 = 0, pend1 = 0, pend2 = 0, pend3 = 0;
+    int npend = 0;
+    auto flush_pending = [&]() __attribute__((always_inline)) {
+        const int base = mycnt - npend;
+        if (npend > 0 && base < half) candq[base] = pend0;
+        if (npend > 1 && base + 1 < half) candq[base + 1] = pend1;
+        if (npend > 2 && base + 2 < half) candq[base + 2] = pend2;
+        if (npend > 3 && base + 3 < half) candq[base + 3] = pend3;
+        npend = 0;
+    };
+    // ---- selection epilogue ----
+    auto score_of = [&](float acc, int row, const float* ax) __attribute__((always_inline)) -> float {
+        if constexpr (kDirect) return -acc;  // smaller distance = better score
+        else if constexpr (MODE == BF_COS) return acc * ax[row];
+        else return acc;
+    };
+    auto consider = [&](float s, int pos, bool lastst) __attribute__((always_inline)) {
+        bool pass = s > thr;
+        if constexpr (!kAux) pass = pass && (!lastst || pos < r_end);
+        if (pass) {
+            const u64 key = make_sel_key(f32_ord(s), (uint32_t)pos);
+            if (npend < 4) {
+                pend3 = pend2;
+                pend2 = pend1;
+                pend1 = pend0;
+                pend0 = key;
+                npend++;
+            } else {
+                // more than four hits in one stage (early rows only): flush, then keep going
+                flush_pending();
+                pend0 = key;
+                npend = 1;
+            }
+            mycnt++;
+            if (use_top8 && s > t8[7]) {
+                float v = s;  // sorted insert, best first
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float hi = fmaxf(t8[i], v);
+                    v = fminf(t8[i], v);
+                    t8[i] = hi;
+                }
+            }
+        }
+    };
+    // compaction when a half-buffer is nearly full, or final
+    auto finish_stage = [&](bool lastst) __attribute__((always_inline)) {
+        const bool need = lastst || (mycnt > half - BF_BN / 2);
+        if (__any(need)) flush_pending();  // compaction reads the buffers
+        if (lastst && !(a.dbg & 64)) {
+            // Final pass, every lane on its own half-buffer: drop the keys that the final
+            // threshold (own bound and the bounds published by the other row splits) rules out.
+            // What is left usually fits in k' and is concatenated without any sorting.
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            const uint32_t t_ord = thr > -INFINITY ? f32_ord(thr) : 0u;
+            const int n = mycnt < half ? mycnt : half;
+            int w = 0;
+            for (int i = 0; i < n; i += 4) {
+                u64 k0 = candq[i], k1 = i + 1 < n ? candq[i + 1] : 0ull;
+                u64 k2 = i + 2 < n ? candq[i + 2] : 0ull, k3 = i + 3 < n ? candq[i + 3] : 0ull;
+                if ((uint32_t)(k0 >> 32) >= t_ord) candq[w++] = k0;
+                if (k1 && (uint32_t)(k1 >> 32) >= t_ord) candq[w++] = k1;
+                if (k2 && (uint32_t)(k2 >> 32) >= t_ord) candq[w++] = k2;
+                if (k3 && (uint32_t)(k3 >> 32) >= t_ord) candq[w++] = k3;
+            }
+            mycnt = w;
+        }
+        const uint32_t t_ord = compact_queries(wave_cand, qstride, a.cap, a.kprime, scratch, need, mycnt, lane);
+        if (t_ord != 0u) thr = fmaxf(thr, ord_f32(t_ord));
+    };
+    // The 16 scores of one finished 32-row block.  Fast path: one max over the block and one
+    // compare; the element-wise path runs only when some lane of the wave has a hit.
+    auto check_block = [&](const f32x16& o, int blk, int stage) __attribute__((always_inline)) {
+        const float* ax = auxs + (stage % 3) * BF_BN;
+        const int row0 = r_begin + stage * BF_BN + blk * 32;
+        const bool lastst = stage == nstages - 1;
+        float sc[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sc[r] = score_of(o[r], blk * 32 + acc_row(r, h), ax);
+        float m01 = fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3]));
+        float m23 = fmaxf(fmaxf(sc[4], sc[5]), fmaxf(sc[6], sc[7]));
+        float m45 = fmaxf(fmaxf(sc[8], sc[9]), fmaxf(sc[10], sc[11]));
+        float m67 = fmaxf(fmaxf(sc[12], sc[13]), fmaxf(sc[14], sc[15]));
+        const float mx = fmaxf(fmaxf(m01, m23), fmaxf(m45, m67));
+        if (__any(mx > thr) && !(a.dbg & 32)) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) consider(sc[r], row0 + acc_row(r, h), lastst);
+            if (use_top8) thr = fmaxf(thr, fminf(t8[7], __shfl_xor(t8[7], 32, 64)));
+            finish_stage(false);
+        }
+    };
+    // ---- one 32-row block of the staged tile: 64 MFMAs into n; behind the first of them, the 16
+    //      scores of the previously finished block o ----
+    auto block_mfma = [&](f32x16& n, const float* ap, int kc_len, bool epi, const f32x16& o, int o_blk, int o_stage) __attribute__((always_inline)) {
+        // fragment reads run one 8-float group ahead of the MFMAs that consume them; the first
+        // group is peeled so that the (large, rarely taken) score check sits outside the unrolled loop
+        f32x4 av = *reinterpret_cast<const f32x4*>(ap);
+        f32x4 pv = av;
+        if (8 < kc_len) pv = *reinterpret_cast<const f32x4*>(ap + 8);
+        n = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0], bq[0][0], n, 0, 0, 0);
+        n = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1], bq[0][1], n, 0, 0, 0);
+        n = __builtin_amdgcn_mfma_f32_32x32x2f32(av[2], bq[0][2], n, 0, 0, 0);
+        n = __builtin_amdgcn_mfma_f32_32x32x2f32(av[3], bq[0][3], n, 0, 0, 0);
+        if (epi) check_block(o, o_blk, o_stage);
+        av = pv;
+#pragma unroll
+        for (int tt = 1; tt < 16; ++tt) {
+            if (tt + 1 < 16 && 8 * (tt + 1) < kc_len) pv = *reinterpret_cast<const f32x4*>(ap + 8 * (tt + 1));
+            if (8 * tt < kc_len) {
+                n = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0], bq[tt][0], n, 0, 0, 0);
+                n = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1], bq[tt][1], n, 0, 0, 0);
+                n = __builtin_amdgcn_mfma_f32_32x32x2f32(av[2], bq[tt][2], n, 0, 0, 0);
+                n = __builtin_amdgcn_mfma_f32_32x32x2f32(av[3], bq[tt][3], n, 0, 0, 0);
+            }
+            av = pv;
+        }
+    };
+    // -0.5*||b||^2 folded in with one more MFMA: A = (aux | 0), B = (1 | 0)
+    auto add_norm = [&](f32x16& n, int blk, int stage) __attribute__((always_inline)) {
+        if constexpr (MODE == BF_L2) {
+            const float* ax = auxs + (stage % 3) * BF_BN;
+            const float one = h == 0 ? 1.f : 0.f;
+            const float x = h == 0 ? ax[blk * 32 + l31] : 0.f;
+            n = __builtin_amdgcn_mfma_f32_32x32x2f32(x, one, n, 0, 0, 0);
+        }
+    };
+    // direct (VALU) modes: lanes of one half read the same LDS addresses (broadcast reads); each
+    // lane accumulates full-dimension |a-b| for its own 16 rows of the block
+    auto block_direct = [&](f32x16& n, const float* t, int blk, int kc_len) __attribute__((always_inline)) {
+        if constexpr (kDirect) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float* ap = t + (blk * 32 + acc_row(r, h)) * lds_stride;
+                float s = n[r];
+#pragma unroll
+                for (int tt = 0; tt < 16; ++tt) {
+                    if (8 * tt < kc_len) {
+                        const f32x4 alo = *reinterpret_cast<const f32x4*>(ap + 8 * tt);
+                        const f32x4 ahi = *reinterpret_cast<const f32x4*>(ap + 8 * tt + 4);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float d0 = fabsf(alo[j] - qlo[tt][j]);
+                            const float d1 = fabsf(ahi[j] - qhi[tt][j]);
+                            s = (MODE == BF_L1) ? (s + d0) + d1 : fmaxf(fmaxf(s, d0), d1);
+                        }
+                    }
+                }
+                n[r] = s;
+            }
+        }
+    };
+
+    // X holds block 0 of a stage, Y block 1.  MFMA modes: Y(stage s-1) is examined under the MFMAs
+    // of X(stage s), X(stage s) under the MFMAs of Y(stage s).
+    f32x16 accX, accY;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        accX[i] = 0.f;
+        accY[i] = 0.f;
+    }
 
     if (nsteps > 0) {
         issue_loads(0);
         write_lds(0);
     }
-    if (a.nchunks == 1) {
+    if (nchunks == 1) {
         load_queries(0);
+        // Retire the query loads HERE, with the builtin the waitcnt pass models: otherwise it
+        // keeps a progressive vmcnt(N) ladder inside the row loop (first use of each fragment)
+        // that also drains the next tile's prefetch far too early.
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) only
         spread_queries();
     }
     __syncthreads();
 
+    const bool skip_epi = (a.dbg & 1) != 0;
     for (int step = 0; step < nsteps; ++step) {
-        const int stage = step / a.nchunks, kc = step - stage * a.nchunks;
+        const int stage = step / nchunks, kc = step - stage * nchunks;
         const bool have_next = step + 1 < nsteps;
-        if (have_next) issue_loads(step + 1);
-        if (a.nchunks > 1) {
+        if (have_next && !((a.dbg & 2) && step > 0)) issue_loads(step + 1);
+        if (!ONE && nchunks > 1) {
             load_queries(kc);
             spread_queries();
         }
-        const int kc_len = min(kcs, a.ldb - kc * BF_KC);
+        const int kc_len = FULL ? BF_KC : min(kcs, a.ldb - kc * BF_KC);
         const float* t = tile + (step & 1) * BF_BN * lds_stride;
-
-        if (kc == 0) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                acc0[i] = 0.f;
-                acc1[i] = 0.f;
-            }
-        }
-
+        const bool first = kc == 0, lastc = kc == nchunks - 1;
         if constexpr (!kDirect) {
             const float* ap0 = t + l31 * lds_stride + 4 * h;
-            const float* ap1 = ap0 + 32 * lds_stride;
+            if (first) {
 #pragma unroll
-            for (int tt = 0; tt < 16; ++tt) {
-                if (8 * tt < kc_len) {
-                    const f32x4 a0 = *reinterpret_cast<const f32x4*>(ap0 + 8 * tt);
-                    const f32x4 a1 = *reinterpret_cast<const f32x4*>(ap1 + 8 * tt);
-                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[0], bq[tt][0], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[0], bq[tt][0], acc1, 0, 0, 0);
-                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[1], bq[tt][1], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[1], bq[tt][1], acc1, 0, 0, 0);
-                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[2], bq[tt][2], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[2], bq[tt][2], acc1, 0, 0, 0);
-                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[3], bq[tt][3], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[3], bq[tt][3], acc1, 0, 0, 0);
-                }
+                for (int i = 0; i < 16; ++i) accX[i] = 0.f;
             }
+            block_mfma(accX, ap0, kc_len, first && stage > 0 && !skip_epi, accY, 1, stage - 1);
+            if (lastc) add_norm(accX, 0, stage);
+            if (first) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) accY[i] = 0.f;
+            }
+            block_mfma(accY, ap0 + 32 * lds_stride, kc_len, lastc && !skip_epi, accX, 0, stage);
+            if (lastc) add_norm(accY, 1, stage);
+            if (skip_epi) asm volatile("" ::"v"(accX[0]), "v"(accY[0]), "v"(accX[15]), "v"(accY[15]));
         } else {
-            // lanes of one half read the same LDS addresses (broadcast reads); each lane
-            // accumulates full-dimension |a-b| for its own 16 rows per block
+            if (first) {
 #pragma unroll
-            for (int blk = 0; blk < 2; ++blk) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float* ap = t + (blk * 32 + acc_row(r, h)) * lds_stride;
-                    float s = blk == 0 ? acc0[r] : acc1[r];
-#pragma unroll
-                    for (int tt = 0; tt < 16; ++tt) {
-                        if (8 * tt < kc_len) {
-                            const f32x4 alo = *reinterpret_cast<const f32x4*>(ap + 8 * tt);
-                            const f32x4 ahi = *reinterpret_cast<const f32x4*>(ap + 8 * tt + 4);
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) {
-                                const float d0 = fabsf(alo[j] - qlo[tt][j]);
-                                const float d1 = fabsf(ahi[j] - qhi[tt][j]);
-                                s = (MODE == BF_L1) ? (s + d0) + d1 : fmaxf(fmaxf(s, d0), d1);
-                            }
-                        }
-                    }
-                    if (blk == 0) acc0[r] = s; else acc1[r] = s;
+                for (int i = 0; i < 16; ++i) {
+                    accX[i] = 0.f;
+                    accY[i] = 0.f;
                 }
             }
-        }
-
-        if (kc == a.nchunks - 1) {
-            // ---------------- epilogue of this 64-row stage ----------------
-            const float* ax = auxs + (stage & 1) * BF_BN;
-            if constexpr (MODE == BF_L2) {
-                // fold -0.5*||b||^2 in with one more MFMA: A = (aux | 0), B = (1 | 0)
-                const float one = h == 0 ? 1.f : 0.f;
-                const float x0 = h == 0 ? ax[l31] : 0.f;
-                const float x1 = h == 0 ? ax[32 + l31] : 0.f;
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(x0, one, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(x1, one, acc1, 0, 0, 0);
-            }
-            const int row0 = r_begin + stage * BF_BN;
-#pragma unroll
-            for (int blk = 0; blk < 2; ++blk) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = blk * 32 + acc_row(r, h);
-                    float s;
-                    s = blk == 0 ? acc0[r] : acc1[r];
-                    if constexpr (kDirect) s = -s;  // smaller distance = better score
-                    if constexpr (MODE == BF_COS) s *= ax[row];
-                    const int pos = row0 + row;
-                    if (pos < r_end && s > thr) {
-                        const int slot = atomicAdd(my_cnt, 1);
-                        if (slot < a.cap) candq[slot] = make_sel_key(f32_ord(s), (uint32_t)pos);
-                    }
-                }
-            }
-            // make this wave's appended keys visible to its own later loads
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_wave_barrier();
-            const bool last = stage == nstages - 1;
-            const int c = *my_cnt;
-            const bool need = last || (c > a.cap - BF_BN);
-            u64 m = __ballot(need) & 0xFFFFFFFFull;
-            while (m) {
-                const int q = __ffsll((long long)m) - 1;
-                m &= m - 1;
-                int n = cnt[wave * 32 + q];
-                n = n < a.cap ? n : a.cap;
-                u64* g = a.cand + ((size_t)(qt * BF_TQ + wave * 32 + q) * a.nsplit + split) * a.cap;
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                const uint32_t t_ord =
-                    compact_candidates(g, n, a.kprime, scratch, lane, &cnt[wave * 32 + q]);
-                if (l31 == q && t_ord != 0u) thr = ord_f32(t_ord);
+            block_direct(accX, t, 0, kc_len);
+            block_direct(accY, t, 1, kc_len);
+            if (lastc && !skip_epi) {
+                check_block(accX, 0, stage);
+                check_block(accY, 1, stage);
+                if (stage == nstages - 1) finish_stage(true);
             }
         }
-
-        if (have_next) write_lds(step + 1);
-        __syncthreads();
+        if (have_next && !((a.dbg & 2) && step > 0)) write_lds(step + 1);
+        flush_pending();  // after the staging wait: these stores have a whole stage to retire
+        if (!(a.dbg & 8)) __syncthreads();
     }
-
-    __builtin_amdgcn_wave_barrier();
-    if (h == 0) a.cand_cnt[(size_t)qidx * a.nsplit + split] = *my_cnt;
+    // drain: block 1 of the last stage has not been examined yet; then the final compaction
+    if (kDelay && nstages > 0 && !skip_epi) {
+        check_block(accY, 1, nstages - 1);
+        if (!(a.dbg & 16)) finish_stage(true);
+    }
+    if (h == 0) a.cand_cnt[(size_t)qidx * a.nsplit + split] = mycnt;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -321,10 +550,13 @@ __global__ __launch_bounds__(256, 2) void bf_select_u8_kernel(BfArgsU8 a) {
     int* cnt = auxs + 2 * BF_BN;                                            // [TQ]
     u64* scratch = reinterpret_cast<u64*>(cnt + BF_TQ) + (size_t)wave * a.cap;
 
-    if (tid < BF_TQ) cnt[tid] = 0;
+    (void)cnt;
     const int qidx = qt * BF_TQ + wave * 32 + l31;
-    u64* candq = a.cand + ((size_t)qidx * a.nsplit + split) * a.cap;
-    int* my_cnt = &cnt[wave * 32 + l31];
+    const int half = a.cap >> 1;
+    u64* candq = a.cand + ((size_t)qidx * a.nsplit + split) * a.cap + (size_t)h * half;
+    int mycnt = 0;
+    u64* wave_cand = a.cand + ((size_t)(qt * BF_TQ + wave * 32) * a.nsplit + split) * a.cap;
+    const size_t qstride = (size_t)a.nsplit * a.cap;
 
     const int r_begin = split * a.rows_per_split;
     const int r_end = min(a.n, r_begin + a.rows_per_split);
@@ -389,6 +621,7 @@ __global__ __launch_bounds__(256, 2) void bf_select_u8_kernel(BfArgsU8 a) {
         }
         const int* ax = auxs + (stage & 1) * BF_BN;
         const int row0 = r_begin + stage * BF_BN;
+        const bool last = stage == nstages - 1;
 #pragma unroll
         for (int blk = 0; blk < 2; ++blk) {
 #pragma unroll
@@ -400,34 +633,20 @@ __global__ __launch_bounds__(256, 2) void bf_select_u8_kernel(BfArgsU8 a) {
                     const int r = 4 * g + j;
                     const int s = 2 * (blk == 0 ? acc0[r] : acc1[r]) + av[j];
                     const int pos = row0 + blk * 32 + 8 * g + 4 * h + j;
-                    if (pos < r_end && s > thr) {
-                        const int slot = atomicAdd(my_cnt, 1);
-                        if (slot < a.cap) candq[slot] = make_sel_key(i32_ord(s), (uint32_t)pos);
+                    if (s > thr && (!last || pos < r_end)) {
+                        if (mycnt < half) candq[mycnt] = make_sel_key(i32_ord(s), (uint32_t)pos);
+                        mycnt++;
                     }
                 }
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        const bool last = stage == nstages - 1;
-        const int c = *my_cnt;
-        const bool need = last || (c > a.cap - BF_BN);
-        u64 m = __ballot(need) & 0xFFFFFFFFull;
-        while (m) {
-            const int q = __ffsll((long long)m) - 1;
-            m &= m - 1;
-            int n = cnt[wave * 32 + q];
-            n = n < a.cap ? n : a.cap;
-            u64* g = a.cand + ((size_t)(qt * BF_TQ + wave * 32 + q) * a.nsplit + split) * a.cap;
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            const uint32_t t_ord = compact_candidates(g, n, a.kprime, scratch, lane, &cnt[wave * 32 + q]);
-            if (l31 == q && n >= a.kprime) thr = ord_i32(t_ord);
-        }
+        const bool need = last || (mycnt > half - BF_BN / 2);
+        const uint32_t t_ord = compact_queries(wave_cand, qstride, a.cap, a.kprime, scratch, need, mycnt, lane);
+        if (t_ord != 0u) thr = max(thr, ord_i32(t_ord));
         if (have_next) write_lds(stage + 1);
         __syncthreads();
     }
-    __builtin_amdgcn_wave_barrier();
-    if (h == 0) a.cand_cnt[(size_t)qidx * a.nsplit + split] = *my_cnt;
+    if (h == 0) a.cand_cnt[(size_t)qidx * a.nsplit + split] = mycnt;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -647,15 +866,32 @@ BfPlan bf_make_plan(int n, int dim, int nq, int k, bool is_u8) {
     return p;
 }
 
-template <int MODE>
-static hipError_t launch_select_mode(const BfPlan& p, const BfArgs& a, hipStream_t s) {
-    auto kern = bf_select_f32_kernel<MODE>;
+template <int MODE, bool FULL, bool ONE>
+static hipError_t launch_select_kern(const BfPlan& p, const BfArgs& a, hipStream_t s) {
+    auto kern = bf_select_f32_kernel<MODE, FULL, ONE>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_select);
     if (e != hipSuccess) return e;
     const int grid = 8 * p.nqt * (p.nsplit / 8);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), p.lds_select, s, a);
     return hipGetLastError();
+}
+
+template <int MODE>
+static hipError_t launch_select_mode(const BfPlan& p, const BfArgs& a, hipStream_t s) {
+#ifdef BF_FAST_COMPILE  // kernel experiments: only the headline instantiation
+    if (MODE == BF_L2 && p.ldb == BF_KC) return launch_select_kern<BF_L2, true, true>(p, a, s);
+    return hipErrorInvalidValue;
+#else
+    if constexpr (MODE == BF_L1 || MODE == BF_LINF) {
+        // VALU-bound modes: one generic instantiation is enough (and keeps the build short)
+        return launch_select_kern<MODE, false, false>(p, a, s);
+    } else {
+        if (p.ldb == BF_KC) return launch_select_kern<MODE, true, true>(p, a, s);
+        if (p.ldb % BF_KC == 0) return launch_select_kern<MODE, true, false>(p, a, s);
+        return launch_select_kern<MODE, false, false>(p, a, s);
+    }
+#endif
 }
 
 static BfArgs make_args(const BfPlan& p, const float* base, const float* aux, const float* q, u64* cand,
@@ -675,6 +911,8 @@ static BfArgs make_args(const BfPlan& p, const float* base, const float* aux, co
     a.cap = p.cap;
     a.kcs = p.ldb < BF_KC ? p.ldb : BF_KC;
     a.nchunks = (p.ldb + BF_KC - 1) / BF_KC;
+    static const int dbg = getenv("NMSLIB_GPU_DEBUG") ? atoi(getenv("NMSLIB_GPU_DEBUG")) : 0;
+    a.dbg = dbg;
     return a;
 }
 

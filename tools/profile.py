@@ -1,0 +1,107 @@
+#!/usr/bin/env python3
+"""Profile bench.py on the GPU box with rocprofv3 and write compact summaries.
+
+    python3 tools/profile.py [--workload bruteforce|hnsw|sift] [--tag r01] [bench args...]
+
+Passes (each its own rocprofv3 run, as the MI355X guide prescribes: counters never combined
+with traces): kernel-trace --stats, two SQ counter sets, FETCH_SIZE, WRITE_SIZE.  Outputs
+gpurun_out/prof/<tag>_<workload>_{stats,pmc}.json ; copy the ones to keep into profiles/.
+This process never touches the GPU itself: it only spawns rocprofv3 with `python3 bench.py`
+directly after `--`.
+"""
+import csv
+import glob
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PMC_SETS = {
+    "sq1": "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_MFMA",
+    "sq2": "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_VMEM",
+    "grbm": "GRBM_GUI_ACTIVE",
+    "fetch": "FETCH_SIZE",
+    "write": "WRITE_SIZE",
+}
+
+
+def run(cmd, env):
+    print("+", " ".join(cmd), flush=True)
+    r = subprocess.run(cmd, env=env, cwd="/tmp", stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    return r.returncode, r.stdout
+
+
+def main():
+    args = sys.argv[1:]
+    tag, workload = "r01", "bruteforce"
+    if "--tag" in args:
+        i = args.index("--tag")
+        tag = args[i + 1]
+        del args[i:i + 2]
+    if "--workload" in args:
+        workload = args[args.index("--workload") + 1]
+    bench = ["python3", os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "2", "--no-cpu-baseline"] + args
+    out = os.path.join(ROOT, "gpurun_out", "prof")
+    os.makedirs(out, exist_ok=True)
+    env = dict(os.environ, TMPDIR="/tmp")
+
+    # ---- pass 0: kernel trace + stats ----
+    d = os.path.join(out, f"{tag}_{workload}_trace")
+    rc, log = run(["rocprofv3", "--kernel-trace", "--stats", "-d", d, "-o", "t", "--output-format", "csv", "--"] + bench, env)
+    stats = {"rc": rc, "bench_json": None, "kernels": []}
+    for line in log.splitlines():
+        if line.startswith("{") and '"metric"' in line:
+            stats["bench_json"] = json.loads(line)
+    for f in glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True):
+        for row in csv.DictReader(open(f)):
+            stats["kernels"].append({k: row[k] for k in row})
+    per_kernel = {}
+    for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
+        for row in csv.DictReader(open(f)):
+            name = row.get("Kernel_Name", "")
+            dur = (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e3
+            e = per_kernel.setdefault(name, {"calls": 0, "total_us": 0.0, "min_us": 1e30, "max_us": 0.0,
+                                             "vgpr": row.get("VGPR_Count"), "accum_vgpr": row.get("Accum_VGPR_Count"),
+                                             "sgpr": row.get("SGPR_Count"), "lds": row.get("LDS_Block_Size"),
+                                             "grid": row.get("Grid_Size"), "wg": row.get("Workgroup_Size")})
+            e["calls"] += 1
+            e["total_us"] += dur
+            e["min_us"] = min(e["min_us"], dur)
+            e["max_us"] = max(e["max_us"], dur)
+    for e in per_kernel.values():
+        e["avg_us"] = round(e["total_us"] / e["calls"], 2)
+        e["total_us"] = round(e["total_us"], 1)
+    stats["per_kernel"] = dict(sorted(per_kernel.items(), key=lambda kv: -kv[1]["total_us"]))
+    json.dump(stats, open(os.path.join(out, f"{tag}_{workload}_stats.json"), "w"), indent=1)
+
+    # ---- counter passes ----
+    pmc = {}
+    for name, counters in PMC_SETS.items():
+        d = os.path.join(out, f"{tag}_{workload}_pmc_{name}")
+        rc, log = run(["rocprofv3", "--pmc"] + counters.split() + ["-d", d, "-o", "c", "--output-format", "csv", "--"] + bench, env)
+        agg = {}
+        for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+            for row in csv.DictReader(open(f)):
+                k = row.get("Kernel_Name", "")
+                c = row.get("Counter_Name", "")
+                v = float(row.get("Counter_Value", 0) or 0)
+                e = agg.setdefault(k, {}).setdefault(c, [0.0, 0])
+                e[0] += v
+                e[1] += 1
+        for k, cs in agg.items():
+            for c, (tot, n) in cs.items():
+                pmc.setdefault(k, {})[c] = {"per_dispatch": tot / max(1, n), "dispatches": n}
+        if rc != 0:
+            pmc.setdefault("_errors", {})[name] = log[-2000:]
+    json.dump(pmc, open(os.path.join(out, f"{tag}_{workload}_pmc.json"), "w"), indent=1)
+    # brief console summary
+    for k, e in list(stats["per_kernel"].items())[:6]:
+        print(f"{e['avg_us']:>10.1f} us x{e['calls']:<4d} vgpr={e['vgpr']} lds={e['lds']}  {k[:90]}")
+    for k, cs in pmc.items():
+        if "select" in k or "hnsw_search" in k:
+            print(k[:80], {c: round(v["per_dispatch"], 1) for c, v in cs.items()})
+
+
+if __name__ == "__main__":
+    main()
