@@ -33,6 +33,7 @@ struct BfArgs {
     const float* queries;
     u64* cand;
     int* cand_cnt;
+    uint32_t* gthr;  // [qpad] best published threshold per query (order-preserving uint, 0 = none)
     int n, ldb, nqt, nsplit, rows_per_split, kprime, cap;
     int kcs;      // floats staged per K-chunk = min(ldb, 128)
     int nchunks;  // ceil(ldb / 128)
@@ -377,6 +378,22 @@ __global__ __launch_bounds__(256, 2) void bf_select_f32_kernel(BfArgs a) {
             finish_stage(false);
         }
     };
+    // Thresholds are shared between the row splits of a query through gthr (agent-scope atomic
+    // max): ANY split's bound on its k'-th best score also bounds the global k'-th best, so a
+    // foreign bound T may prune with "score >= T" (strict compare against the next lower float).
+    // A stale or missing value only prunes less.  The reply of one exchange is consumed at the
+    // next one, so its latency is never waited for.
+    uint32_t g_reply = 0u;
+    auto exchange_thr = [&]() __attribute__((always_inline)) {
+        const uint32_t g = __shfl(g_reply, l31, 64);
+        if (g > 1u) thr = fmaxf(thr, ord_f32(g - 1u));
+        if (h == 0 && a.gthr) {
+            const uint32_t mine = thr > -INFINITY ? f32_ord(thr) : 0u;
+            const uint32_t old = atomicMax(a.gthr + qidx, mine);
+            g_reply = old > mine ? old : mine;
+        }
+    };
+
     // ---- one 32-row block of the staged tile: 64 MFMAs into n; behind the first of them, the 16
     //      scores of the previously finished block o ----
     auto block_mfma = [&](f32x16& n, const float* ap, int kc_len, bool epi, const f32x16& o, int o_blk, int o_stage) __attribute__((always_inline)) {
@@ -462,6 +479,7 @@ __global__ __launch_bounds__(256, 2) void bf_select_f32_kernel(BfArgs a) {
     __syncthreads();
 
     const bool skip_epi = (a.dbg & 1) != 0;
+    const int xmask = (a.dbg >> 12) ? ((1 << ((a.dbg >> 12) & 7)) - 1) : 3;  // threshold exchange every (xmask+1) stages
     for (int step = 0; step < nsteps; ++step) {
         const int stage = step / nchunks, kc = step - stage * nchunks;
         const bool have_next = step + 1 < nsteps;
@@ -506,6 +524,7 @@ __global__ __launch_bounds__(256, 2) void bf_select_f32_kernel(BfArgs a) {
         }
         if (have_next && !((a.dbg & 2) && step > 0)) write_lds(step + 1);
         flush_pending();  // after the staging wait: these stores have a whole stage to retire
+        if (lastc && (stage & xmask) == xmask && !(a.dbg & 256)) exchange_thr();
         if (!(a.dbg & 8)) __syncthreads();
     }
     // drain: block 1 of the last stage has not been examined yet; then the final compaction
@@ -895,13 +914,14 @@ static hipError_t launch_select_mode(const BfPlan& p, const BfArgs& a, hipStream
 }
 
 static BfArgs make_args(const BfPlan& p, const float* base, const float* aux, const float* q, u64* cand,
-                        int* cnt) {
+                        int* cnt, uint32_t* gthr) {
     BfArgs a{};
     a.base = base;
     a.aux = aux;
     a.queries = q;
     a.cand = cand;
     a.cand_cnt = cnt;
+    a.gthr = gthr;
     a.n = p.n;
     a.ldb = p.ldb;
     a.nqt = p.nqt;
@@ -919,7 +939,11 @@ static BfArgs make_args(const BfPlan& p, const float* base, const float* aux, co
 hipError_t launch_bf_select_f32(const BfPlan& p, int space, const float* base, const float* aux,
                                 const float* queries_padded, unsigned long long* cand, int* cand_cnt,
                                 hipStream_t s) {
-    BfArgs a = make_args(p, base, aux, queries_padded, cand, cand_cnt);
+    // per-query shared thresholds live behind the survivor counts; cleared for every batch
+    uint32_t* gthr = reinterpret_cast<uint32_t*>(cand_cnt + (size_t)p.qpad * p.nsplit);
+    hipError_t me = hipMemsetAsync(gthr, 0, (size_t)p.qpad * 4, s);
+    if (me != hipSuccess) return me;
+    BfArgs a = make_args(p, base, aux, queries_padded, cand, cand_cnt, gthr);
     switch (space) {
         case SP_L2: return launch_select_mode<BF_L2>(p, a, s);
         case SP_NEGDOT: return launch_select_mode<BF_DOT>(p, a, s);
@@ -932,7 +956,10 @@ hipError_t launch_bf_select_f32(const BfPlan& p, int space, const float* base, c
 hipError_t launch_bf_select_direct_f32(const BfPlan& p, int space, const float* base,
                                        const float* queries_padded, unsigned long long* cand,
                                        int* cand_cnt, hipStream_t s) {
-    BfArgs a = make_args(p, base, nullptr, queries_padded, cand, cand_cnt);
+    uint32_t* gthr = reinterpret_cast<uint32_t*>(cand_cnt + (size_t)p.qpad * p.nsplit);
+    hipError_t me = hipMemsetAsync(gthr, 0, (size_t)p.qpad * 4, s);
+    if (me != hipSuccess) return me;
+    BfArgs a = make_args(p, base, nullptr, queries_padded, cand, cand_cnt, gthr);
     if (space == SP_L1) return launch_select_mode<BF_L1>(p, a, s);
     if (space == SP_LINF) return launch_select_mode<BF_LINF>(p, a, s);
     return hipErrorInvalidValue;
