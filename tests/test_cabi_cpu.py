@@ -227,3 +227,14 @@ def test_no_gpu_means_loud_failure_not_fallback():
     with pytest.raises(nz.NmslibError):
         idx.getDistance(0, 1)
     idx.close()
+
+
+def test_cpp_host_mirror_compiles_and_links(tmp_path):
+    """nmslib_zig_amd/host/nmslib.hpp (the C++ mirror of lib.zig) against the shared library."""
+    import subprocess
+    exe = str(tmp_path / "host_mirror_check")
+    libdir = os.path.join(ROOT, "nmslib_zig_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", os.path.join(ROOT, "tests", "host_mirror_check.cpp"), "-o", exe,
+                           "-L" + libdir, "-lnmslib_c", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0 and "host mirror ok" in out.stdout, out.stdout + out.stderr
