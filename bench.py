@@ -37,6 +37,11 @@ PEAK_I8_MFMA_TOPS = 5000.0     # i8 = 2x bf16 dense (~2.5 PF) per MI355X_MICROAR
 PEAK_HBM_GBS = 8000.0          # HBM3E spec
 
 
+def note(msg):
+    """progress line on stderr (long host-side phases must not look hung)"""
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -126,6 +131,7 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)   # RCCL over xGMI
 
+    note(f"generating data: workload={a.workload} n={a.n}")
     X, Q = make_data(a)
     n, nq, k = X.shape[0], Q.shape[0], a.k
     lo, hi = rank * n // world, (rank + 1) * n // world          # this rank's row shard
@@ -136,6 +142,7 @@ def main():
                    dist_type="Int" if u8 else "Float")
     ids = np.arange(lo, hi, dtype=np.int32)                      # external id = global row
     (idx.addUInt8Batch if u8 else idx.addDenseBatch)(X[lo:hi], ids)
+    note("building index (rows -> HBM" + (", host HNSW construction" if method == "hnsw" else "") + ")")
     t_build = time.time()
     if method == "hnsw":
         idx.buildIndex(M=16, efConstruction=200)
@@ -143,6 +150,7 @@ def main():
     else:
         idx.buildIndex()
     t_build = time.time() - t_build
+    note(f"index ready in {t_build:.1f}s; timing {a.steps} steps")
 
     dq = torch.from_numpy(Q).to(dev)
     d_ids = torch.empty((nq, k), dtype=torch.int32, device=dev)
@@ -264,6 +272,7 @@ def main():
         "roofline": roof,
     }
     if world == 1 and not a.no_cpu_baseline:
+        note("timing the CPU baseline (oracle/_ref) on a bounded sample")
         try:
             out["cpu_baseline"] = cpu_baseline(a, X, Q, gt_ids, gt_d)
         except Exception as e:  # the baseline must never take the GPU number down with it
