@@ -37,7 +37,7 @@ struct HnswArgs {
 };
 
 constexpr uint32_t HT_EMPTY = 0xFFFFFFFFu;
-constexpr int SA_EMAX = 16;  // sorted array up to 64*16 = 1024 items
+constexpr int SA_EMAX_MAX = 16;  // sorted array up to 64*16 = 1024 items
 
 template <int SPACE>
 struct DistTraits {
@@ -79,22 +79,36 @@ __device__ __forceinline__ float finish_dist(float s0, float s1, float s2) {
     else return s0;
 }
 
+// 8-lane reductions with DPP (VALU speed; __shfl_xor would go through the LDS crossbar):
+// row_half_mirror pairs lane i with 7-i inside each group of 8, then quad_perm swaps 1 and 2 apart.
+template <typename T>
+__device__ __forceinline__ T dpp_half_mirror(T v) {
+    return __builtin_bit_cast(T, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
+}
+template <typename T>
+__device__ __forceinline__ T dpp_quad_xor1(T v) {  // quad_perm [1,0,3,2]
+    return __builtin_bit_cast(T, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+}
+template <typename T>
+__device__ __forceinline__ T dpp_quad_xor2(T v) {  // quad_perm [2,3,0,1]
+    return __builtin_bit_cast(T, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+}
 __device__ __forceinline__ float group8_sum(float v) {
-    v += __shfl_xor(v, 4, 64);
-    v += __shfl_xor(v, 2, 64);
-    v += __shfl_xor(v, 1, 64);
+    v += dpp_half_mirror(v);
+    v += dpp_quad_xor1(v);
+    v += dpp_quad_xor2(v);
     return v;
 }
 __device__ __forceinline__ float group8_max(float v) {
-    v = fmaxf(v, __shfl_xor(v, 4, 64));
-    v = fmaxf(v, __shfl_xor(v, 2, 64));
-    v = fmaxf(v, __shfl_xor(v, 1, 64));
+    v = fmaxf(v, dpp_half_mirror(v));
+    v = fmaxf(v, dpp_quad_xor1(v));
+    v = fmaxf(v, dpp_quad_xor2(v));
     return v;
 }
 __device__ __forceinline__ int group8_sum_i(int v) {
-    v += __shfl_xor(v, 4, 64);
-    v += __shfl_xor(v, 2, 64);
-    v += __shfl_xor(v, 1, 64);
+    v += dpp_half_mirror(v);
+    v += dpp_quad_xor1(v);
+    v += dpp_quad_xor2(v);
     return v;
 }
 
@@ -165,7 +179,8 @@ __device__ __forceinline__ void frontier_distances(const HnswDeviceGraph& g, con
     }
 }
 
-template <int SPACE, bool BITSET>
+// EMAX = sorted-array items per lane (cap <= 64*EMAX): 2 for ef <= 128, 4 for <= 256, 16 otherwise.
+template <int SPACE, bool BITSET, int SA_EMAX>
 __global__ __launch_bounds__(64) void hnsw_search_kernel(HnswArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const HnswDeviceGraph& g = a.g;
@@ -305,28 +320,47 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(HnswArgs a) {
     }
     __builtin_amdgcn_wave_barrier();
 
+    // cur: every item before it is used (the reference's currElem).  pre_*: adjacency of the item
+    // that will most likely be expanded next, requested one expansion early (its latency hides
+    // behind this expansion's gather); a wrong guess only costs the normal load.
+    int cursor = 0;
+    int pre_node = -1, pre_v = 0;
     while (true) {
         const int lim = n < a.ef ? n : a.ef;
-        // first unused item
+        // first unused item at or after cur
         int fu = n;
-#pragma unroll
-        for (int e = 0; e < SA_EMAX; ++e) {
-            if (e * 64 < n && fu == n) {
-                const int i = lane + 64 * e;
-                const bool un = i < n && idu[i] >= 0;
-                const u64 mk = __ballot(un);
-                if (mk) fu = 64 * e + (__ffsll((long long)mk) - 1);
-            }
+        for (int base = cursor; base < n && fu == n; base += 64) {
+            const int i = base + lane;
+            const u64 mk = __ballot(i < n && idu[i] >= 0);
+            if (mk) fu = base + (__ffsll((long long)mk) - 1);
         }
         if (fu >= lim) break;
         const int c = idu[fu] & 0x7FFFFFFF;
         if (lane == 0) idu[fu] |= (int)0x80000000;
+        cursor = fu + 1;
         hops++;
         const float topKey = keys[n - 1];
         const int size0 = n;
 
         // adjacency of c: [count][ids...]
-        const int v = (lane <= g.maxM0) ? g.links0[(size_t)c * (g.maxM0 + 1) + lane] : 0;
+        int v;
+        if (c == pre_node) v = pre_v;
+        else v = (lane <= g.maxM0) ? g.links0[(size_t)c * (g.maxM0 + 1) + lane] : 0;
+        // guess the next expansion: the next unused item (true unless a closer one is inserted)
+        {
+            int fu2 = n;
+            for (int base = cursor; base < n && fu2 == n; base += 64) {
+                const int i = base + lane;
+                const u64 mk = __ballot(i < n && idu[i] >= 0);
+                if (mk) fu2 = base + (__ffsll((long long)mk) - 1);
+            }
+            if (fu2 < lim) {
+                pre_node = idu[fu2] & 0x7FFFFFFF;
+                pre_v = (lane <= g.maxM0) ? g.links0[(size_t)pre_node * (g.maxM0 + 1) + lane] : 0;
+            } else {
+                pre_node = -1;
+            }
+        }
         const int cntn = __builtin_amdgcn_readfirstlane(v);
         const int nb = __shfl(v, lane + 1, 64);
         bool isn = false;
@@ -385,24 +419,31 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(HnswArgs a) {
                     n++;
                 }
             } else {
-                // exponential probe from the tail, then lower_bound inside [curr, prev): with
-                // runs of equal keys this lands where the reference lands (sort_arr_bi.h:172-186)
-                int curr = n - 1, prev = curr, dstep = 1;
-                while (curr > 0 && keys[curr] > key) {
-                    prev = curr;
-                    curr -= dstep;
-                    dstep *= 2;
-                    if (dstep > curr) dstep = curr;
-                }
-                int p = curr;
-                if (curr < prev) {
+                // insertion index.  Without a key equal to the new one in the array, the reference's
+                // exponential probe + lower_bound (sort_arr_bi.h:172-186) is simply the number of
+                // smaller keys: one parallel count.  With equal keys present (rare) the probe is
+                // replayed so the item lands inside the run exactly where the reference puts it.
+                int less = 0, leq = 0;
 #pragma unroll
-                    for (int e = 0; e < SA_EMAX; ++e) {
-                        if (curr + e * 64 < prev) {
-                            const int i = curr + lane + 64 * e;
-                            p += __popcll(__ballot(i < prev && keys[i] < key));
-                        }
+                for (int e = 0; e < SA_EMAX; ++e) {
+                    if (e * 64 < n) {
+                        const int i = lane + 64 * e;
+                        const float kv = i < n ? keys[i] : INFINITY;
+                        less += __popcll(__ballot(kv < key));
+                        leq += __popcll(__ballot(kv <= key));
                     }
+                }
+                int p = less;
+                if (leq != less) {
+                    int curr = n - 1, prev = curr, dstep = 1;
+                    while (curr > 0 && keys[curr] > key) {
+                        prev = curr;
+                        curr -= dstep;
+                        dstep *= 2;
+                        if (dstep > curr) dstep = curr;
+                    }
+                    p = curr;
+                    for (int i = curr; i < prev && keys[i] < key; ++i) p = i + 1;
                 }
                 const int newn = n < a.cap ? n + 1 : a.cap;
                 float rk[SA_EMAX];
@@ -433,6 +474,7 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(HnswArgs a) {
                     idu[p] = id;
                 }
                 n = newn;
+                if (p < cursor) cursor = p;  // :261-266
             }
             __builtin_amdgcn_wave_barrier();
         }
@@ -501,17 +543,17 @@ HnswSearchPlan hnsw_make_plan(const HnswDeviceGraph& g, int nq, int k, int ef, b
     return p;
 }
 
-template <int SPACE>
-static hipError_t launch_space(const HnswArgs& a, const HnswSearchPlan& p, hipStream_t s) {
+template <int SPACE, int EMAX>
+static hipError_t launch_space_e(const HnswArgs& a, const HnswSearchPlan& p, hipStream_t s) {
     hipError_t e;
     if (p.table_size == 0) {
-        auto kern = hnsw_search_kernel<SPACE, true>;
+        auto kern = hnsw_search_kernel<SPACE, true, EMAX>;
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(kern, dim3(a.nq), dim3(64), p.lds_bytes, s, a);
     } else {
-        auto kern = hnsw_search_kernel<SPACE, false>;
+        auto kern = hnsw_search_kernel<SPACE, false, EMAX>;
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
         if (e != hipSuccess) return e;
@@ -520,12 +562,19 @@ static hipError_t launch_space(const HnswArgs& a, const HnswSearchPlan& p, hipSt
     return hipGetLastError();
 }
 
+template <int SPACE>
+static hipError_t launch_space(const HnswArgs& a, const HnswSearchPlan& p, hipStream_t s) {
+    if (p.cap <= 128) return launch_space_e<SPACE, 2>(a, p, s);
+    if (p.cap <= 256) return launch_space_e<SPACE, 4>(a, p, s);
+    return launch_space_e<SPACE, SA_EMAX_MAX>(a, p, s);
+}
+
 hipError_t launch_hnsw_search(const HnswDeviceGraph& g, const HnswSearchPlan& p, const void* queries,
                               uint32_t* bitset, int32_t* out_ids, float* out_dists, int32_t* out_cnt,
                               int32_t* out_ndc, int32_t* out_hops, int32_t* out_hops_up,
                               int32_t* status, hipStream_t s) {
     if (p.nq == 0) return hipSuccess;
-    if (p.cap > 64 * SA_EMAX || g.maxM0 > 62 || g.maxM > 62) return hipErrorInvalidValue;
+    if (p.cap > 64 * SA_EMAX_MAX || g.maxM0 > 62 || g.maxM > 62) return hipErrorInvalidValue;
     HnswArgs a{};
     a.g = g;
     a.queries = queries;
