@@ -54,6 +54,7 @@ def parse():
     ap.add_argument("--k", type=int, default=None)
     ap.add_argument("--ef", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--index-cache", default="", help="hnsw, 1 GPU: save the built index here / load it if present")
     ap.add_argument("--cpu-sample", type=int, default=0, help="queries in the CPU baseline sample (0 = auto)")
     return ap.parse_args()
 
@@ -138,17 +139,26 @@ def main():
     u8 = a.workload == "sift"
     space = "l2sqr_sift" if u8 else "l2"
     method = "hnsw" if a.workload == "hnsw" else "seq_search"
-    idx = nz.Index(space, method, data_type="DenseUInt8Vector" if u8 else "DenseVector",
-                   dist_type="Int" if u8 else "Float")
-    ids = np.arange(lo, hi, dtype=np.int32)                      # external id = global row
-    (idx.addUInt8Batch if u8 else idx.addDenseBatch)(X[lo:hi], ids)
-    note("building index (rows -> HBM" + (", host HNSW construction" if method == "hnsw" else "") + ")")
+    cache = a.index_cache if (method == "hnsw" and world == 1) else ""
     t_build = time.time()
-    if method == "hnsw":
-        idx.buildIndex(M=16, efConstruction=200)
+    if cache and os.path.exists(cache):
+        note(f"loading cached index {cache}")
+        idx = nz.Index.load(cache, load_data=False)              # the reference's optimized-index format
+        idx.finalize()
         idx.setQueryTimeParams(efSearch=a.ef)
     else:
-        idx.buildIndex()
+        idx = nz.Index(space, method, data_type="DenseUInt8Vector" if u8 else "DenseVector",
+                       dist_type="Int" if u8 else "Float")
+        ids = np.arange(lo, hi, dtype=np.int32)                      # external id = global row
+        (idx.addUInt8Batch if u8 else idx.addDenseBatch)(X[lo:hi], ids)
+        note("building index (rows -> HBM" + (", host HNSW construction" if method == "hnsw" else "") + ")")
+        if method == "hnsw":
+            idx.buildIndex(M=16, efConstruction=200)
+            idx.setQueryTimeParams(efSearch=a.ef)
+            if cache:
+                idx.save(cache, False)
+        else:
+            idx.buildIndex()
     t_build = time.time() - t_build
     note(f"index ready in {t_build:.1f}s; timing {a.steps} steps")
 
