@@ -1,0 +1,316 @@
+// HNSW construction on the GPU: batched insertion.
+//
+// Restates Hnsw::add (src/method/hnsw.cc:534-609) for a whole batch of new nodes at once.  Per
+// level, top down, three launches:
+//   1. search    - kSearchElementsWithAttemptsLevel (hnsw.cc:611-708) for every new node of the
+//                  batch = the search kernel in construction mode (hnsw_kernels.hip): the query is
+//                  a stored row, ef = efConstruction, the whole result set is returned;
+//   2. select    - HnswNode::getNeighborsByHeuristic2 (include/method/hnsw.h:129-169) on each result
+//                  set -> the new node's forward list, plus one queued reverse-link request per
+//                  selected neighbour;
+//   3. link      - HnswNode::addFriendlevel (hnsw.h:258-314) target by target: append, or shrink
+//                  with the same heuristic when the list is full.
+// The nodes of one batch do not see each other while searching (like the reference's concurrent
+// inserts, which lock one node at a time); reverse links of a batch are applied per target in
+// ascending new-node order, so the construction is deterministic.  One wavefront per node/target;
+// no workgroup ever waits for another inside a launch.
+#include "hnsw_common.cuh"
+#include "kernels.hpp"
+
+namespace gfxknn {
+
+struct BuildArgs {
+    HnswDeviceGraph g;
+    int32_t* links0;
+    int32_t* up_links;
+    int M, delaunay, level;
+    const int32_t* pts;
+    int npts;
+    const int32_t* cand_ids;
+    const float* cand_d;
+    const int32_t* cand_n;
+    int stride;
+    int32_t* req_cnt;
+    int32_t* req_node;
+    float* req_dist;
+    int req_cap;
+    int32_t* active;
+    int32_t* nactive;
+};
+
+__device__ __forceinline__ int32_t* adj_list(const BuildArgs& a, int node) {
+    if (a.level == 0) return a.links0 + (size_t)node * (a.g.maxM0 + 1);
+    return a.up_links + a.g.up_off[node] + (int64_t)(a.level - 1) * (a.g.maxM + 1);
+}
+
+// Stored row `node` becomes the "query" of frontier_distances (LDS copy; u8: bytes + norm).
+template <int SPACE>
+__device__ __forceinline__ void stage_row(const HnswDeviceGraph& g, int node, float* qv, int& qnorm, int lane) {
+    if constexpr (DistTraits<SPACE>::kU8) {
+        const uint8_t* src = reinterpret_cast<const uint8_t*>(g.rows) + (size_t)node * 128;
+        reinterpret_cast<uint16_t*>(qv)[lane] = reinterpret_cast<const uint16_t*>(src)[lane];
+        qnorm = g.row_norm[node];
+    } else {
+        const float* src = reinterpret_cast<const float*>(g.rows) + (size_t)node * g.ldv;
+        for (int d = lane; d < g.ldv; d += 64) qv[d] = src[d];
+        qnorm = 0;
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+// getNeighborsByHeuristic2 over candidates sorted by ascending distance to the centre node.
+// A candidate is kept unless some already kept node is strictly closer to it than the centre is.
+// Fewer than NN candidates: all are kept (hnsw.h:133-135).  delaunay_type 0: the NN closest.
+template <int SPACE>
+__device__ __forceinline__ int heuristic2(const HnswDeviceGraph& g, const int* cid, const float* cd, int nc, int NN,
+                                          int delaunay, float* qv, float* nd, int* kept_id, float* kept_d, int lane) {
+    if (nc < NN || delaunay == 0) {
+        const int n = nc < NN ? nc : NN;
+        for (int i = lane; i < n; i += 64) {
+            kept_id[i] = cid[i];
+            kept_d[i] = cd[i];
+        }
+        __builtin_amdgcn_wave_barrier();
+        return n;
+    }
+    int nk = 0;
+    for (int i = 0; i < nc && nk < NN; ++i) {
+        const int c = cid[i];
+        const float dc = cd[i];
+        bool good = true;
+        if (nk > 0) {
+            int qnorm;
+            stage_row<SPACE>(g, c, qv, qnorm, lane);
+            frontier_distances<SPACE>(g, qv, reinterpret_cast<const uint8_t*>(qv), qnorm, kept_id, nd, nk, lane);
+            bool bad = false;
+            for (int j = lane; j < nk; j += 64) bad |= nd[j] < dc;
+            good = !__any(bad);
+        }
+        if (good) {
+            if (lane == 0) {
+                kept_id[nk] = c;
+                kept_d[nk] = dc;
+            }
+            nk++;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    return nk;
+}
+
+template <int SPACE>
+__global__ __launch_bounds__(64) void hnsw_build_select_kernel(BuildArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const HnswDeviceGraph& g = a.g;
+    const int q = blockIdx.x, lane = threadIdx.x;
+    const int qfloats = DistTraits<SPACE>::kU8 ? 32 : g.ldv;
+    float* qv = reinterpret_cast<float*>(smem);                 // [ldv]
+    float* nd = qv + qfloats;                                   // [64]
+    int* kept_id = reinterpret_cast<int*>(nd + 64);             // [64]
+    float* kept_d = reinterpret_cast<float*>(kept_id + 64);     // [64]
+    int* lc_id = reinterpret_cast<int*>(kept_d + 64);           // [stride]
+    float* lc_d = reinterpret_cast<float*>(lc_id + a.stride);   // [stride]
+
+    const int p = a.pts[q];
+    const int nc = a.cand_n[q];
+    for (int i = lane; i < nc; i += 64) {
+        lc_id[i] = a.cand_ids[(size_t)q * a.stride + i];
+        lc_d[i] = a.cand_d[(size_t)q * a.stride + i];
+    }
+    __builtin_amdgcn_wave_barrier();
+    const int nk = heuristic2<SPACE>(g, lc_id, lc_d, nc, a.M, a.delaunay, qv, nd, kept_id, kept_d, lane);
+
+    // forward list of the new node: link() is called farthest first (hnsw.cc:597-601)
+    int32_t* L = adj_list(a, p);
+    if (lane == 0) L[0] = nk;
+    if (lane < nk) L[1 + lane] = kept_id[nk - 1 - lane];
+    // one reverse-link request per selected neighbour
+    if (lane < nk) {
+        const int t = kept_id[lane];
+        const int slot = atomicAdd(&a.req_cnt[t], 1);
+        if (slot < a.req_cap) {
+            a.req_node[(size_t)t * a.req_cap + slot] = p;
+            a.req_dist[(size_t)t * a.req_cap + slot] = kept_d[lane];
+        }
+        if (slot == 0) a.active[atomicAdd(a.nactive, 1)] = t;
+    }
+}
+
+template <int SPACE>
+__global__ __launch_bounds__(64) void hnsw_build_link_kernel(BuildArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const HnswDeviceGraph& g = a.g;
+    const int lane = threadIdx.x;
+    if ((int)blockIdx.x >= *a.nactive) return;
+    const int qfloats = DistTraits<SPACE>::kU8 ? 32 : g.ldv;
+    float* qv = reinterpret_cast<float*>(smem);                 // [ldv]
+    float* nd = qv + qfloats;                                   // [64]
+    int* kept_id = reinterpret_cast<int*>(nd + 64);             // [64]
+    float* kept_d = reinterpret_cast<float*>(kept_id + 64);     // [64]
+    int* fl = reinterpret_cast<int*>(kept_d + 64);              // [64] current friends
+    int* sc_id = fl + 64;                                       // [64] friends + new node, sorted
+    float* sc_d = reinterpret_cast<float*>(sc_id + 64);         // [64]
+    int* rp = reinterpret_cast<int*>(sc_d + 64);                // [64] requests, sorted by new node
+    float* rd = reinterpret_cast<float*>(rp + 64);              // [64]
+
+    const int t = a.active[blockIdx.x];
+    int nreq = a.req_cnt[t];
+    nreq = nreq < a.req_cap ? nreq : a.req_cap;
+    {   // requests in ascending new-node order (deterministic)
+        int pj = 0x7FFFFFFF;
+        float dj = 0.f;
+        if (lane < nreq) {
+            pj = a.req_node[(size_t)t * a.req_cap + lane];
+            dj = a.req_dist[(size_t)t * a.req_cap + lane];
+        }
+        int rank = 0;
+        for (int i = 0; i < nreq; ++i) rank += (__shfl(pj, i, 64) < pj) ? 1 : 0;
+        if (lane < nreq) {
+            rp[rank] = pj;
+            rd[rank] = dj;
+        }
+    }
+    int32_t* L = adj_list(a, t);
+    const int maxsz = a.level > 0 ? g.maxM : g.maxM0;
+    int cnt = L[0];
+    if (lane < cnt) fl[lane] = L[1 + lane];
+    __builtin_amdgcn_wave_barrier();
+
+    for (int r = 0; r < nreq; ++r) {
+        const int p = rp[r];
+        const float dp = rd[r];
+        if (cnt < maxsz) {
+            if (lane == 0) fl[cnt] = p;
+            cnt++;
+            __builtin_amdgcn_wave_barrier();
+            continue;
+        }
+        // full: distances of the centre t to its friends, the new node joins, heuristic over cnt+1
+        int qnorm;
+        stage_row<SPACE>(g, t, qv, qnorm, lane);
+        frontier_distances<SPACE>(g, qv, reinterpret_cast<const uint8_t*>(qv), qnorm, fl, nd, cnt, lane);
+        int idj = -1;
+        float dj = INFINITY;
+        if (lane < cnt) {
+            idj = fl[lane];
+            dj = nd[lane];
+        } else if (lane == cnt) {
+            idj = p;
+            dj = dp;
+        }
+        const int n1 = cnt + 1;
+        int rank = 0;
+        for (int i = 0; i < n1; ++i) {
+            const float di = __shfl(dj, i, 64);
+            rank += (di < dj || (di == dj && i < lane)) ? 1 : 0;
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (lane < n1) {
+            sc_id[rank] = idj;
+            sc_d[rank] = dj;
+        }
+        __builtin_amdgcn_wave_barrier();
+        const int nk = heuristic2<SPACE>(g, sc_id, sc_d, n1, n1 - 1, a.delaunay, qv, nd, kept_id, kept_d, lane);
+        // refilled farthest first (hnsw.h:295-300)
+        if (lane < nk) fl[lane] = kept_id[nk - 1 - lane];
+        cnt = nk;
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (lane == 0) {
+        L[0] = cnt;
+        a.req_cnt[t] = 0;
+    }
+    if (lane < maxsz) L[1 + lane] = lane < cnt ? fl[lane] : 0;
+}
+
+// start node of each (node, level) search = closest result of the same node's search one level up
+__global__ void hnsw_build_starts_kernel(const int32_t* src, const int32_t* cand_ids, const int32_t* cand_n,
+                                         int stride, int32_t* starts, int m) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    const int sp = src[i];
+    starts[i] = (sp >= 0 && cand_n[sp] > 0) ? cand_ids[(size_t)sp * stride] : -1;
+}
+
+hipError_t launch_hnsw_build_starts(const int32_t* src, const int32_t* cand_ids, const int32_t* cand_n, int stride,
+                                    int32_t* starts, int m, hipStream_t s) {
+    if (m <= 0) return hipSuccess;
+    hipLaunchKernelGGL(hnsw_build_starts_kernel, dim3((m + 255) / 256), dim3(256), 0, s, src, cand_ids, cand_n,
+                       stride, starts, m);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------
+template <typename Kern>
+static hipError_t launch_build(Kern kern, const BuildArgs& a, int grid, size_t lds, hipStream_t s) {
+    if (grid <= 0) return hipSuccess;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64), lds, s, a);
+    return hipGetLastError();
+}
+
+#define BUILD_DISPATCH(KERNEL, SPACEVAR, ARGS, GRID, LDS, STREAM)                                  \
+    switch (SPACEVAR) {                                                                            \
+        case SP_L2SQR: return launch_build(KERNEL<SP_L2SQR>, ARGS, GRID, LDS, STREAM);             \
+        case SP_L2: return launch_build(KERNEL<SP_L2>, ARGS, GRID, LDS, STREAM);                   \
+        case SP_L1: return launch_build(KERNEL<SP_L1>, ARGS, GRID, LDS, STREAM);                   \
+        case SP_LINF: return launch_build(KERNEL<SP_LINF>, ARGS, GRID, LDS, STREAM);               \
+        case SP_NORMCOS: return launch_build(KERNEL<SP_NORMCOS>, ARGS, GRID, LDS, STREAM);         \
+        case SP_COSINE: return launch_build(KERNEL<SP_COSINE>, ARGS, GRID, LDS, STREAM);           \
+        case SP_ANGULAR: return launch_build(KERNEL<SP_ANGULAR>, ARGS, GRID, LDS, STREAM);         \
+        case SP_NEGDOT: return launch_build(KERNEL<SP_NEGDOT>, ARGS, GRID, LDS, STREAM);           \
+        case SP_L2SQR_SIFT: return launch_build(KERNEL<SP_L2SQR_SIFT>, ARGS, GRID, LDS, STREAM);   \
+        default: return hipErrorInvalidValue;                                                      \
+    }
+
+static BuildArgs base_args(const HnswBuildGraph& bg, int level) {
+    BuildArgs a{};
+    a.g = bg.g;
+    a.links0 = bg.links0;
+    a.up_links = bg.up_links;
+    a.M = bg.M;
+    a.delaunay = bg.delaunay;
+    a.level = level;
+    return a;
+}
+
+hipError_t launch_hnsw_build_select(const HnswBuildGraph& bg, int level, const int32_t* pts, int npts,
+                                    const int32_t* cand_ids, const float* cand_d, const int32_t* cand_n,
+                                    int stride, int32_t* req_cnt, int32_t* req_node, float* req_dist,
+                                    int req_cap, int32_t* active, int32_t* nactive, hipStream_t s) {
+    BuildArgs a = base_args(bg, level);
+    a.pts = pts;
+    a.npts = npts;
+    a.cand_ids = cand_ids;
+    a.cand_d = cand_d;
+    a.cand_n = cand_n;
+    a.stride = stride;
+    a.req_cnt = req_cnt;
+    a.req_node = req_node;
+    a.req_dist = req_dist;
+    a.req_cap = req_cap;
+    a.active = active;
+    a.nactive = nactive;
+    const size_t qbytes = bg.g.space == SP_L2SQR_SIFT ? 128 : (size_t)bg.g.ldv * 4;
+    const size_t lds = qbytes + 3 * 64 * 4 + (size_t)stride * 8 + 16;
+    BUILD_DISPATCH(hnsw_build_select_kernel, bg.g.space, a, npts, lds, s)
+}
+
+hipError_t launch_hnsw_build_link(const HnswBuildGraph& bg, int level, const int32_t* active,
+                                  const int32_t* nactive, int max_active, int32_t* req_cnt,
+                                  const int32_t* req_node, const float* req_dist, int req_cap, hipStream_t s) {
+    BuildArgs a = base_args(bg, level);
+    a.active = const_cast<int32_t*>(active);
+    a.nactive = const_cast<int32_t*>(nactive);
+    a.req_cnt = req_cnt;
+    a.req_node = const_cast<int32_t*>(req_node);
+    a.req_dist = const_cast<float*>(req_dist);
+    a.req_cap = req_cap;
+    const size_t qbytes = bg.g.space == SP_L2SQR_SIFT ? 128 : (size_t)bg.g.ldv * 4;
+    const size_t lds = qbytes + 9 * 64 * 4 + 16;
+    BUILD_DISPATCH(hnsw_build_link_kernel, bg.g.space, a, max_active, lds, s)
+}
+
+}  // namespace gfxknn

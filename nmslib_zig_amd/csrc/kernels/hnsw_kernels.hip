@@ -14,7 +14,7 @@
 // per lane per step, up to 32 rows in flight per wave - with the distance fused into the
 // gather and an 8-lane shuffle reduction.  The sorted array lives in LDS and is shifted by
 // all lanes at once.  ndc / hops counters feed the roofline.
-#include "common.cuh"
+#include "hnsw_common.cuh"
 #include "kernels.hpp"
 
 namespace gfxknn {
@@ -33,151 +33,16 @@ struct HnswArgs {
     int32_t* status;
     int nq, k, ef, cap;
     int capa;  // cap rounded up to a multiple of 4 (keeps the LDS carve-up 16-byte aligned)
+    // construction mode (hnsw_build_kernels.hip): the query is a stored row, the best-first phase runs
+    // on `level`, and the start node is given (or found by descending from the entry point to level+1)
+    const int32_t* query_rows;   // [nq] row index of each query, or NULL (external queries)
+    const int32_t* start_nodes;  // [nq] start node (>= 0) or -1 = descend from the entry point; or NULL
+    int level;
     int table_size, table_shift;
 };
 
 constexpr uint32_t HT_EMPTY = 0xFFFFFFFFu;
 constexpr int SA_EMAX_MAX = 16;  // sorted array up to 64*16 = 1024 items
-
-template <int SPACE>
-struct DistTraits {
-    static constexpr bool kU8 = (SPACE == SP_L2SQR_SIFT);
-    static constexpr bool kThree = (SPACE == SP_COSINE || SPACE == SP_ANGULAR);
-    static constexpr bool kMax = (SPACE == SP_LINF);
-};
-
-template <int SPACE>
-__device__ __forceinline__ void accum4(const f32x4& q, const f32x4& b, float& s0, float& s1, float& s2) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        if constexpr (SPACE == SP_L2SQR || SPACE == SP_L2) {
-            const float t = q[j] - b[j];
-            s0 = fmaf(t, t, s0);
-        } else if constexpr (SPACE == SP_L1) {
-            s0 += fabsf(q[j] - b[j]);
-        } else if constexpr (SPACE == SP_LINF) {
-            s0 = fmaxf(s0, fabsf(q[j] - b[j]));
-        } else if constexpr (SPACE == SP_NORMCOS || SPACE == SP_NEGDOT) {
-            s0 = fmaf(q[j], b[j], s0);
-        } else {  // cosine / angular on raw rows: dot, |row|^2, |query|^2
-            s0 = fmaf(b[j], q[j], s0);
-            s1 = fmaf(b[j], b[j], s1);
-            s2 = fmaf(q[j], q[j], s2);
-        }
-    }
-}
-
-template <int SPACE>
-__device__ __forceinline__ float finish_dist(float s0, float s1, float s2) {
-    if constexpr (SPACE == SP_L2) return sqrtf(s0);
-    else if constexpr (SPACE == SP_NEGDOT) return -s0;
-    else if constexpr (SPACE == SP_NORMCOS) {
-        const float c = fmaxf(-1.0f, fminf(1.0f, s0));
-        return fmaxf(0.0f, 1.0f - c);
-    } else if constexpr (SPACE == SP_COSINE) return fmaxf(0.0f, 1.0f - normdot_finish(s0, s1, s2));
-    else if constexpr (SPACE == SP_ANGULAR) return acosf(normdot_finish(s0, s1, s2));
-    else return s0;
-}
-
-// 8-lane reductions with DPP (VALU speed; __shfl_xor would go through the LDS crossbar):
-// row_half_mirror pairs lane i with 7-i inside each group of 8, then quad_perm swaps 1 and 2 apart.
-template <typename T>
-__device__ __forceinline__ T dpp_half_mirror(T v) {
-    return __builtin_bit_cast(T, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
-}
-template <typename T>
-__device__ __forceinline__ T dpp_quad_xor1(T v) {  // quad_perm [1,0,3,2]
-    return __builtin_bit_cast(T, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
-}
-template <typename T>
-__device__ __forceinline__ T dpp_quad_xor2(T v) {  // quad_perm [2,3,0,1]
-    return __builtin_bit_cast(T, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
-}
-__device__ __forceinline__ float group8_sum(float v) {
-    v += dpp_half_mirror(v);
-    v += dpp_quad_xor1(v);
-    v += dpp_quad_xor2(v);
-    return v;
-}
-__device__ __forceinline__ float group8_max(float v) {
-    v = fmaxf(v, dpp_half_mirror(v));
-    v = fmaxf(v, dpp_quad_xor1(v));
-    v = fmaxf(v, dpp_quad_xor2(v));
-    return v;
-}
-__device__ __forceinline__ int group8_sum_i(int v) {
-    v += dpp_half_mirror(v);
-    v += dpp_quad_xor1(v);
-    v += dpp_quad_xor2(v);
-    return v;
-}
-
-// Distances of the query to the m rows listed in nbr[0..m) -> nd[0..m).
-// 8 lanes per row; 8 rows per pass; 4 passes issued together (32 rows in flight).
-template <int SPACE>
-__device__ __forceinline__ void frontier_distances(const HnswDeviceGraph& g, const float* qv,
-                                                   const uint8_t* qb, int qnorm, const int* nbr,
-                                                   float* nd, int m, int lane) {
-    const int g8 = lane >> 3, sub = lane & 7;
-    for (int base_i = 0; base_i < m; base_i += 32) {
-        int ids[4];
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const int idx = base_i + p * 8 + g8;
-            ids[p] = idx < m ? nbr[idx] : -1;
-        }
-        if constexpr (DistTraits<SPACE>::kU8) {
-            // 128-byte rows: one 16-byte load per lane; exact integer n1 + n2 - 2*dot
-            const i32x4 qq = *reinterpret_cast<const i32x4*>(qb + sub * 16);
-            int dots[4];
-#pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                int dsum = 0;
-                if (ids[p] >= 0) {
-                    const i32x4 bb = *reinterpret_cast<const i32x4*>(
-                        reinterpret_cast<const uint8_t*>(g.rows) + (size_t)ids[p] * 128 + sub * 16);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) dsum = __builtin_amdgcn_udot4(qq[j], bb[j], dsum, false);
-                }
-                dots[p] = dsum;
-            }
-#pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                const int dot = group8_sum_i(dots[p]);
-                const int idx = base_i + p * 8 + g8;
-                if (sub == 0 && idx < m) nd[idx] = (float)(g.row_norm[ids[p]] + qnorm - 2 * dot);
-            }
-        } else {
-            float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
-            const float* rows = reinterpret_cast<const float*>(g.rows);
-#pragma unroll 4
-            for (int d = sub * 4; d < g.ldv; d += 32) {
-                const f32x4 qq = *reinterpret_cast<const f32x4*>(qv + d);
-                f32x4 bb[4];
-#pragma unroll
-                for (int p = 0; p < 4; ++p) {
-                    bb[p] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    if (ids[p] >= 0) bb[p] = *reinterpret_cast<const f32x4*>(rows + (size_t)ids[p] * g.ldv + d);
-                }
-#pragma unroll
-                for (int p = 0; p < 4; ++p) accum4<SPACE>(qq, bb[p], s0[p], s1[p], s2[p]);
-            }
-#pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                float r0, r1 = 0.f, r2 = 0.f;
-                if constexpr (DistTraits<SPACE>::kMax) r0 = group8_max(s0[p]);
-                else r0 = group8_sum(s0[p]);
-                if constexpr (DistTraits<SPACE>::kThree) {
-                    r1 = group8_sum(s1[p]);
-                    r2 = group8_sum(s2[p]);
-                }
-                const int idx = base_i + p * 8 + g8;
-                if (sub == 0 && idx < m) nd[idx] = finish_dist<SPACE>(r0, r1, r2);
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
-}
 
 // EMAX = sorted-array items per lane (cap <= 64*EMAX): 2 for ef <= 128, 4 for <= 256, 16 otherwise.
 template <int SPACE, bool BITSET, int SA_EMAX>
@@ -202,20 +67,22 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(HnswArgs a) {
     // ---- stage the query ----
     int qnorm = 0;
     if constexpr (kU8) {
-        const uint8_t* src = reinterpret_cast<const uint8_t*>(a.queries) + (size_t)q * 128;
+        const uint8_t* src = a.query_rows ? reinterpret_cast<const uint8_t*>(g.rows) + (size_t)a.query_rows[q] * 128
+                                          : reinterpret_cast<const uint8_t*>(a.queries) + (size_t)q * 128;
         const int x0 = src[2 * lane], x1 = src[2 * lane + 1];
         reinterpret_cast<uint8_t*>(qv)[2 * lane] = (uint8_t)x0;
         reinterpret_cast<uint8_t*>(qv)[2 * lane + 1] = (uint8_t)x1;
         qnorm = wave_sum_i(x0 * x0 + x1 * x1);
     } else {
-        const float* src = reinterpret_cast<const float*>(a.queries) + (size_t)q * g.dim;
+        const float* src = a.query_rows ? reinterpret_cast<const float*>(g.rows) + (size_t)a.query_rows[q] * g.ldv
+                                        : reinterpret_cast<const float*>(a.queries) + (size_t)q * g.dim;
         float ss = 0.f;
         for (int d = lane; d < g.ldv; d += 64) {
             const float v = d < g.dim ? src[d] : 0.f;
             qv[d] = v;
             ss = fmaf(v, v, ss);
         }
-        if (g.normalize_query) {  // hnsw_distfunc_opt.cc:160-162
+        if (g.normalize_query && !a.query_rows) {  // hnsw_distfunc_opt.cc:160-162 (stored rows are already normalised)
             ss = wave_sum(ss);
             if (ss != 0.0f) {
                 const float inv = 1.0f / sqrtf(ss);
@@ -267,13 +134,14 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(HnswArgs a) {
     }
 
     // ---- entry point + greedy descent (hnsw_distfunc_opt.cc:168-198) ----
-    int cur = g.enterpoint;
+    const int start = a.start_nodes ? a.start_nodes[q] : -1;
+    int cur = start >= 0 ? start : g.enterpoint;
     if (lane == 0) nbr[0] = cur;
     __builtin_amdgcn_wave_barrier();
     frontier_distances<SPACE>(g, qv, qb, qnorm, nbr, nd, 1, lane);
     float curdist = nd[0];
     ndc += 1;
-    for (int lvl = g.maxlevel; lvl > 0; --lvl) {
+    for (int lvl = (start >= 0 ? 0 : g.maxlevel); lvl > a.level; --lvl) {
         bool changed = true;
         while (changed) {
             changed = false;
@@ -323,6 +191,11 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(HnswArgs a) {
     // cur: every item before it is used (the reference's currElem).  pre_*: adjacency of the item
     // that will most likely be expanded next, requested one expansion early (its latency hides
     // behind this expansion's gather); a wrong guess only costs the normal load.
+    // adjacency word `lane` of node c on the level being searched ([count][ids...])
+    auto load_adj = [&](int c) -> int {
+        if (a.level == 0) return (lane <= g.maxM0) ? g.links0[(size_t)c * (g.maxM0 + 1) + lane] : 0;
+        return (lane <= g.maxM) ? g.up_links[g.up_off[c] + (int64_t)(a.level - 1) * (g.maxM + 1) + lane] : 0;
+    };
     int cursor = 0;
     int pre_node = -1, pre_v = 0;
     while (true) {
@@ -345,7 +218,7 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(HnswArgs a) {
         // adjacency of c: [count][ids...]
         int v;
         if (c == pre_node) v = pre_v;
-        else v = (lane <= g.maxM0) ? g.links0[(size_t)c * (g.maxM0 + 1) + lane] : 0;
+        else v = load_adj(c);
         // guess the next expansion: the next unused item (true unless a closer one is inserted)
         {
             int fu2 = n;
@@ -356,7 +229,7 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(HnswArgs a) {
             }
             if (fu2 < lim) {
                 pre_node = idu[fu2] & 0x7FFFFFFF;
-                pre_v = (lane <= g.maxM0) ? g.links0[(size_t)pre_node * (g.maxM0 + 1) + lane] : 0;
+                pre_v = load_adj(pre_node);
             } else {
                 pre_node = -1;
             }
@@ -569,7 +442,8 @@ static hipError_t launch_space(const HnswArgs& a, const HnswSearchPlan& p, hipSt
     return launch_space_e<SPACE, SA_EMAX_MAX>(a, p, s);
 }
 
-hipError_t launch_hnsw_search(const HnswDeviceGraph& g, const HnswSearchPlan& p, const void* queries,
+hipError_t launch_hnsw_search_ex(const HnswDeviceGraph& g, const HnswSearchPlan& p, const void* queries,
+                                 const int32_t* query_rows, const int32_t* start_nodes, int level,
                               uint32_t* bitset, int32_t* out_ids, float* out_dists, int32_t* out_cnt,
                               int32_t* out_ndc, int32_t* out_hops, int32_t* out_hops_up,
                               int32_t* status, hipStream_t s) {
@@ -578,6 +452,9 @@ hipError_t launch_hnsw_search(const HnswDeviceGraph& g, const HnswSearchPlan& p,
     HnswArgs a{};
     a.g = g;
     a.queries = queries;
+    a.query_rows = query_rows;
+    a.start_nodes = start_nodes;
+    a.level = level;
     a.bitset = bitset;
     a.bitset_words = p.bitset_words;
     a.out_ids = out_ids;
@@ -606,6 +483,14 @@ hipError_t launch_hnsw_search(const HnswDeviceGraph& g, const HnswSearchPlan& p,
         case SP_L2SQR_SIFT: return launch_space<SP_L2SQR_SIFT>(a, p, s);
         default: return hipErrorInvalidValue;
     }
+}
+
+hipError_t launch_hnsw_search(const HnswDeviceGraph& g, const HnswSearchPlan& p, const void* queries,
+                              uint32_t* bitset, int32_t* out_ids, float* out_dists, int32_t* out_cnt,
+                              int32_t* out_ndc, int32_t* out_hops, int32_t* out_hops_up, int32_t* status,
+                              hipStream_t s) {
+    return launch_hnsw_search_ex(g, p, queries, nullptr, nullptr, 0, bitset, out_ids, out_dists, out_cnt, out_ndc,
+                                 out_hops, out_hops_up, status, s);
 }
 
 }  // namespace gfxknn

@@ -108,6 +108,36 @@ hipError_t launch_hnsw_search(const HnswDeviceGraph& g, const HnswSearchPlan& p,
                               int32_t* out_hops, int32_t* out_hops_up, int32_t* status,
                               hipStream_t s);
 
+// Construction-mode search (hnsw_build): queries are stored rows (query_rows), the best-first phase runs on
+// `level`, start_nodes[q] >= 0 gives the start node (else descend from the entry point to level+1).
+hipError_t launch_hnsw_search_ex(const HnswDeviceGraph& g, const HnswSearchPlan& p, const void* queries,
+                                 const int32_t* query_rows, const int32_t* start_nodes, int level,
+                                 uint32_t* bitset, int32_t* out_ids, float* out_dists, int32_t* out_cnt,
+                                 int32_t* out_ndc, int32_t* out_hops, int32_t* out_hops_up, int32_t* status,
+                                 hipStream_t s);
+
+// ---- HNSW construction on the GPU (hnsw_build_kernels.hip) ------------------------------------
+struct HnswBuildGraph {          // mutable twin of HnswDeviceGraph
+    HnswDeviceGraph g;           // rows, links0, up_off, up_links (written by the link kernels)
+    int32_t* links0;             // same memory as g.links0, non-const
+    int32_t* up_links;
+    int M, delaunay;
+};
+// starts[i] = first (closest) candidate of pair src[i] (src[i] < 0 or empty -> -1 = descend from the entry point)
+hipError_t launch_hnsw_build_starts(const int32_t* src, const int32_t* cand_ids, const int32_t* cand_n, int stride,
+                                    int32_t* starts, int m, hipStream_t s);
+// Heuristic neighbour selection for the `npts` new nodes listed in pts at `level`: reads the sorted candidates
+// (cand_ids/cand_d/cand_n, stride `stride`), writes each new node's forward list, queues one reverse-link
+// request per selected neighbour (req_*: per-target slots, `req_cap` each; active/nactive: targets touched).
+hipError_t launch_hnsw_build_select(const HnswBuildGraph& bg, int level, const int32_t* pts, int npts,
+                                    const int32_t* cand_ids, const float* cand_d, const int32_t* cand_n,
+                                    int stride, int32_t* req_cnt, int32_t* req_node, float* req_dist,
+                                    int req_cap, int32_t* active, int32_t* nactive, hipStream_t s);
+// Apply the queued reverse links target by target (addFriendlevel + shrink, hnsw.h:258-314); resets req_cnt.
+hipError_t launch_hnsw_build_link(const HnswBuildGraph& bg, int level, const int32_t* active,
+                                  const int32_t* nactive, int max_active, int32_t* req_cnt,
+                                  const int32_t* req_node, const float* req_dist, int req_cap, hipStream_t s);
+
 // ---- shard merge ---------------------------------------------------------------------------
 hipError_t launch_merge_topk(const float* dists_in, const int32_t* ids_in, int nshards, int nq,
                              int k, float* dists_out, int32_t* ids_out, hipStream_t s);
