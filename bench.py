@@ -55,6 +55,7 @@ def parse():
     ap.add_argument("--ef", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--index-cache", default="", help="hnsw, 1 GPU: save the built index here / load it if present")
+    ap.add_argument("--gpu-build", type=int, default=-1, help="hnsw: 1 = batched GPU construction, 0 = host, -1 = library default")
     ap.add_argument("--cpu-sample", type=int, default=0, help="queries in the CPU baseline sample (0 = auto)")
     return ap.parse_args()
 
@@ -151,9 +152,10 @@ def main():
                        dist_type="Int" if u8 else "Float")
         ids = np.arange(lo, hi, dtype=np.int32)                      # external id = global row
         (idx.addUInt8Batch if u8 else idx.addDenseBatch)(X[lo:hi], ids)
-        note("building index (rows -> HBM" + (", host HNSW construction" if method == "hnsw" else "") + ")")
+        note("building index (rows -> HBM" + (", HNSW construction" if method == "hnsw" else "") + ")")
         if method == "hnsw":
-            idx.buildIndex(M=16, efConstruction=200)
+            idx.buildIndex(M=16, efConstruction=200, **({"gpu_build": a.gpu_build} if a.gpu_build >= 0 else {}))
+            note(f"graph built in {idx.stats()['build_seconds']:.2f}s")
             idx.setQueryTimeParams(efSearch=a.ef)
             if cache:
                 idx.save(cache, False)

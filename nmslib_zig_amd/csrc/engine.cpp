@@ -254,7 +254,10 @@ void Engine::create_index(const std::vector<std::string>& params) {
         ps.get("skip_optimized_index", skip);
         bp.skip_optimized = skip != 0;
         ps.get("gpu_defer", defer);  // engine extension: build now, upload to HBM at first use
+        ps.get("gpu_build", bp.gpu_build);  // engine extension: batched construction on the GPU (1), host (0)
+        ps.get("gpu_build_batch", bp.gpu_build_batch);
         ps.check_unused();
+        if (defer && bp.gpu_build < 0) bp.gpu_build = 0;  // deferred upload = no device work now
         bp_ = bp;
         ef_ = 200;  // the shim forces efSearch=200 per query (nmslib_c.cpp:330,986)
         algo_ = "hybrid";
@@ -363,20 +366,9 @@ void Engine::build_graph() {
     build_seconds = std::chrono::duration<double>(clk::now() - t0).count();
 }
 
-void Engine::upload_graph() {
-    const HostGraph& g = graph_;
-    const size_t n = (size_t)g.n;
-    d_links0_.ensure(std::max<size_t>(g.links0.size(), 1) * 4);
-    d_up_off_.ensure(std::max<size_t>(n, 1) * 8);
-    d_up_links_.ensure(std::max<size_t>(g.up_links.size(), 1) * 4);
-    if (n) {
-        hip_check(hipMemcpy(d_links0_.ptr(), g.links0.data(), g.links0.size() * 4, hipMemcpyHostToDevice), "links0");
-        hip_check(hipMemcpy(d_up_off_.ptr(), g.up_off.data(), n * 8, hipMemcpyHostToDevice), "up_off");
-        if (!g.up_links.empty())
-            hip_check(hipMemcpy(d_up_links_.ptr(), g.up_links.data(), g.up_links.size() * 4, hipMemcpyHostToDevice),
-                      "up_links");
-    }
+void Engine::prepare_graph_rows() {
     // search-time distance of the flat ("optimized") index, hnsw.cc:369-412
+    const size_t n = ids_.size();
     int sspace = space_;
     bool normalize = false;
     const bool optimized = !bp_.skip_optimized;
@@ -402,24 +394,241 @@ void Engine::upload_graph() {
     dg_ = HnswDeviceGraph{};
     dg_.rows = d_rows_.ptr();
     dg_.row_norm = d_rownorm_.as<int32_t>();
-    dg_.links0 = d_links0_.as<int32_t>();
-    dg_.up_off = d_up_off_.as<int64_t>();
-    dg_.up_links = d_up_links_.as<int32_t>();
     dg_.ext_ids = d_ids_.as<int32_t>();
     dg_.n = (int)n;
     dg_.dim = (int)dim_;
     dg_.ldv = is_u8() ? 128 : ldb_;
+    dg_.space = sspace;
+    dg_.normalize_query = normalize ? 1 : 0;
+}
+
+void Engine::upload_graph() {
+    const HostGraph& g = graph_;
+    const size_t n = (size_t)g.n;
+    d_links0_.ensure(std::max<size_t>(g.links0.size(), 1) * 4);
+    d_up_off_.ensure(std::max<size_t>(n, 1) * 8);
+    d_up_links_.ensure(std::max<size_t>(g.up_links.size(), 1) * 4);
+    if (n) {
+        hip_check(hipMemcpy(d_links0_.ptr(), g.links0.data(), g.links0.size() * 4, hipMemcpyHostToDevice), "links0");
+        hip_check(hipMemcpy(d_up_off_.ptr(), g.up_off.data(), n * 8, hipMemcpyHostToDevice), "up_off");
+        if (!g.up_links.empty())
+            hip_check(hipMemcpy(d_up_links_.ptr(), g.up_links.data(), g.up_links.size() * 4, hipMemcpyHostToDevice),
+                      "up_links");
+    }
+    prepare_graph_rows();
+    dg_.links0 = d_links0_.as<int32_t>();
+    dg_.up_off = d_up_off_.as<int64_t>();
+    dg_.up_links = d_up_links_.as<int32_t>();
     dg_.maxM = g.maxM;
     dg_.maxM0 = g.maxM0;
     dg_.maxlevel = g.maxlevel;
     dg_.enterpoint = g.enterpoint;
-    dg_.space = sspace;
-    dg_.normalize_query = normalize ? 1 : 0;
     hip_check(hipStreamSynchronize(stream_), "graph upload");
+}
+
+bool Engine::use_gpu_build() const {
+    if (loaded_graph_ || method_ != Method::Hnsw) return false;
+    if (bp_.gpu_build >= 0) return bp_.gpu_build != 0;
+    // auto: indexThreadQty=1 asks for the reference's sequential insertion order (bit-identical graph,
+    // host builder); anything else is the concurrent build, whose schedule is free -> the GPU
+    return bp_.threads != 1;
+}
+
+// Batched construction on the GPU (kernels/hnsw_build_kernels.hip).  Insertion order, level stream and
+// per-node algorithm are the reference's (Hnsw::add, hnsw.cc:534-609); what differs is visibility:
+// the nodes of one batch are searched against the graph as it was before the batch, then linked.
+// Batches grow with the graph (size/16, at most gpu_build_batch), a node that raises the top level
+// closes its batch.  All searches of a batch (every level, top down) precede all link updates.
+void Engine::build_graph_gpu() {
+    auto t0 = clk::now();
+    const size_t n = ids_.size();
+    hnsw_check_params(bp_);
+    const int M = bp_.M, maxM = bp_.maxM, maxM0 = bp_.maxM0, efC = bp_.efConstruction;
+    if (efC < 1 || efC > 1024)
+        throw EngineError(Err::IndexBuildFailed, "HNSW: efConstruction must be in [1, 1024] for the GPU builder");
+    HostGraph& g = graph_;
+    g = HostGraph{};
+    g.n = (int)n;
+    g.M = M;
+    g.maxM = maxM;
+    g.maxM0 = maxM0;
+    g.efConstruction = efC;
+    g.delaunay = bp_.delaunay;
+    g.levels = hnsw_random_levels(n, bp_);
+    g.up_off.assign(n, -1);
+    size_t up_ints = 0;
+    for (size_t i = 0; i < n; ++i)
+        if (g.levels[i] > 0) {
+            g.up_off[i] = (int64_t)up_ints;
+            up_ints += (size_t)g.levels[i] * (maxM + 1);
+        }
+    const size_t l0_ints = n * (size_t)(maxM0 + 1);
+    d_links0_.ensure(std::max<size_t>(l0_ints, 1) * 4);
+    d_up_off_.ensure(std::max<size_t>(n, 1) * 8);
+    d_up_links_.ensure(std::max<size_t>(up_ints, 1) * 4);
+    prepare_graph_rows();
+    dg_.links0 = d_links0_.as<int32_t>();
+    dg_.up_off = d_up_off_.as<int64_t>();
+    dg_.up_links = d_up_links_.as<int32_t>();
+    dg_.maxM = maxM;
+    dg_.maxM0 = maxM0;
+    if (n == 0) {
+        build_seconds = 0;
+        return;
+    }
+    hipStream_t s = stream_;
+    hip_check(hipMemsetAsync(d_links0_.ptr(), 0, l0_ints * 4, s), "clear links0");
+    hip_check(hipMemsetAsync(d_up_links_.ptr(), 0, std::max<size_t>(up_ints, 1) * 4, s), "clear up_links");
+    hip_check(hipMemcpyAsync(d_up_off_.ptr(), g.up_off.data(), n * 8, hipMemcpyHostToDevice, s), "up_off");
+
+    HnswDeviceGraph bgraph = dg_;
+    bgraph.ext_ids = nullptr;  // construction works on internal positions
+    int maxlevel = g.levels[0], enterpoint = 0;
+    const int max_batch = bp_.gpu_build_batch > 0 ? bp_.gpu_build_batch : 4096;
+    const int req_cap = 32;
+    wb_req_cnt_.ensure(n * 4);
+    wb_req_node_.ensure(n * (size_t)req_cap * 4);
+    wb_req_dist_.ensure(n * (size_t)req_cap * 4);
+    wb_active_.ensure(n * 4);
+    wb_nactive_.ensure(64);
+    hip_check(hipMemsetAsync(wb_req_cnt_.ptr(), 0, n * 4, s), "clear requests");
+
+    std::vector<int32_t> pts, src, status;
+    std::vector<size_t> base;
+    size_t next = 1;
+    while (next < n) {
+        const size_t sz = next;
+        size_t bsz = std::min<size_t>(std::max<size_t>(sz / 16, 1), (size_t)max_batch);
+        size_t end = std::min(n, next + bsz);
+        for (size_t i = next; i < end; ++i)
+            if (g.levels[i] > maxlevel) {
+                end = i + 1;
+                break;
+            }
+        // (node, level) pairs of the batch, level-major (top level first); src = the same node's pair one level up
+        const int top = maxlevel;
+        pts.clear();
+        src.clear();
+        base.assign((size_t)top + 2, 0);
+        std::vector<int32_t> prev_slot(end - next, -1), cur_slot(end - next, -1);
+        for (int l = top; l >= 0; --l) {
+            base[l] = pts.size();
+            for (size_t i = next; i < end; ++i) {
+                if (std::min(g.levels[i], top) < l) continue;
+                cur_slot[i - next] = (int32_t)pts.size();
+                pts.push_back((int32_t)i);
+                src.push_back(prev_slot[i - next]);
+            }
+            prev_slot = cur_slot;
+            std::fill(cur_slot.begin(), cur_slot.end(), -1);
+        }
+        // base[l] .. base[l-1] (or npairs for l == 0) is level l's slice
+        const size_t npairs = pts.size();
+        auto slice_end = [&](int l) { return l == 0 ? npairs : base[l - 1]; };
+        wb_pts_.ensure(npairs * 4);
+        wb_src_.ensure(npairs * 4);
+        wb_starts_.ensure(npairs * 4);
+        wb_cand_ids_.ensure(npairs * (size_t)efC * 4);
+        wb_cand_d_.ensure(npairs * (size_t)efC * 4);
+        wb_cand_n_.ensure(npairs * 4);
+        wb_status_.ensure(npairs * 4);
+        ws_ndc_.ensure(npairs * 4);
+        ws_hops_.ensure(npairs * 4);
+        ws_hops_up_.ensure(npairs * 4);
+        hip_check(hipMemcpyAsync(wb_pts_.ptr(), pts.data(), npairs * 4, hipMemcpyHostToDevice, s), "batch nodes");
+        hip_check(hipMemcpyAsync(wb_src_.ptr(), src.data(), npairs * 4, hipMemcpyHostToDevice, s), "batch sources");
+        bgraph.maxlevel = maxlevel;
+        bgraph.enterpoint = enterpoint;
+
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            const bool force_bitset = attempt == 1;
+            bool used_table = false;
+            for (int l = top; l >= 0; --l) {
+                const size_t b0 = base[l], m = slice_end(l) - b0;
+                if (m == 0) continue;
+                hip_check(launch_hnsw_build_starts(wb_src_.as<int32_t>() + b0, wb_cand_ids_.as<int32_t>(),
+                                                   wb_cand_n_.as<int32_t>(), efC, wb_starts_.as<int32_t>() + b0, (int)m, s),
+                          "build starts");
+                HnswSearchPlan p = hnsw_make_plan(bgraph, (int)m, efC, efC, force_bitset);
+                uint32_t* bitset = nullptr;
+                if (p.table_size == 0) {
+                    ws_bitset_.ensure(m * p.bitset_words * 4);
+                    hip_check(hipMemsetAsync(ws_bitset_.ptr(), 0, m * p.bitset_words * 4, s), "clear visited bitset");
+                    bitset = ws_bitset_.as<uint32_t>();
+                } else {
+                    used_table = true;
+                }
+                hip_check(launch_hnsw_search_ex(bgraph, p, nullptr, wb_pts_.as<int32_t>() + b0,
+                                                wb_starts_.as<int32_t>() + b0, l, bitset,
+                                                wb_cand_ids_.as<int32_t>() + b0 * efC, wb_cand_d_.as<float>() + b0 * efC,
+                                                wb_cand_n_.as<int32_t>() + b0, ws_ndc_.as<int32_t>() + b0,
+                                                ws_hops_.as<int32_t>() + b0, ws_hops_up_.as<int32_t>() + b0,
+                                                wb_status_.as<int32_t>() + b0, s),
+                          "build search");
+            }
+            if (!used_table) break;
+            status.resize(npairs);
+            hip_check(hipMemcpyAsync(status.data(), wb_status_.ptr(), npairs * 4, hipMemcpyDeviceToHost, s), "status");
+            hip_check(hipStreamSynchronize(s), "build search");
+            bool any = false;
+            for (int32_t v : status) any |= (v != 0);
+            if (!any) break;  // else: the LDS visited table overflowed somewhere -> redo with HBM bitsets
+        }
+
+        HnswBuildGraph bg{};
+        bg.g = bgraph;
+        bg.links0 = d_links0_.as<int32_t>();
+        bg.up_links = d_up_links_.as<int32_t>();
+        bg.M = M;
+        bg.delaunay = bp_.delaunay;
+        for (int l = top; l >= 0; --l) {
+            const size_t b0 = base[l], m = slice_end(l) - b0;
+            if (m == 0) continue;
+            hip_check(hipMemsetAsync(wb_nactive_.ptr(), 0, 4, s), "clear active count");
+            hip_check(launch_hnsw_build_select(bg, l, wb_pts_.as<int32_t>() + b0, (int)m,
+                                               wb_cand_ids_.as<int32_t>() + b0 * efC, wb_cand_d_.as<float>() + b0 * efC,
+                                               wb_cand_n_.as<int32_t>() + b0, efC, wb_req_cnt_.as<int32_t>(),
+                                               wb_req_node_.as<int32_t>(), wb_req_dist_.as<float>(), req_cap,
+                                               wb_active_.as<int32_t>(), wb_nactive_.as<int32_t>(), s),
+                      "build select");
+            const size_t max_active = std::min<size_t>(sz, m * (size_t)M);
+            hip_check(launch_hnsw_build_link(bg, l, wb_active_.as<int32_t>(), wb_nactive_.as<int32_t>(), (int)max_active,
+                                             wb_req_cnt_.as<int32_t>(), wb_req_node_.as<int32_t>(),
+                                             wb_req_dist_.as<float>(), req_cap, s),
+                      "build link");
+        }
+        for (size_t i = next; i < end; ++i)
+            if (g.levels[i] > maxlevel) {
+                maxlevel = g.levels[i];
+                enterpoint = (int)i;
+            }
+        // pts/src are reused by the next batch: the copies above must have been consumed
+        hip_check(hipStreamSynchronize(s), "build batch");
+        next = end;
+    }
+    g.maxlevel = maxlevel;
+    g.enterpoint = enterpoint;
+    g.links0.resize(l0_ints);
+    g.up_links.resize(up_ints);
+    hip_check(hipMemcpyAsync(g.links0.data(), d_links0_.ptr(), l0_ints * 4, hipMemcpyDeviceToHost, s), "links0 D2H");
+    if (up_ints)
+        hip_check(hipMemcpyAsync(g.up_links.data(), d_up_links_.ptr(), up_ints * 4, hipMemcpyDeviceToHost, s),
+                  "up_links D2H");
+    hip_check(hipStreamSynchronize(s), "graph download");
+    dg_.maxlevel = maxlevel;
+    dg_.enterpoint = enterpoint;
+    for (DevBuf* b : {&wb_pts_, &wb_src_, &wb_starts_, &wb_cand_ids_, &wb_cand_d_, &wb_cand_n_, &wb_status_,
+                      &wb_req_cnt_, &wb_req_node_, &wb_req_dist_, &wb_active_, &wb_nactive_})
+        b->release();
+    build_seconds = std::chrono::duration<double>(clk::now() - t0).count();
 }
 
 void Engine::ensure_graph() {
     if (method_ != Method::Hnsw || !graph_dirty_) return;
+    if (use_gpu_build()) {
+        finalize();
+        return;
+    }
     build_graph();
     graph_dirty_ = false;
 }
@@ -427,6 +636,14 @@ void Engine::ensure_graph() {
 void Engine::finalize() {
     if (!created_) throw EngineError(Err::IndexBuildFailed, "Index not built");
     if (!dirty_) return;
+    if (method_ == Method::Hnsw && graph_dirty_ && use_gpu_build()) {
+        check_device();
+        upload_rows();
+        build_graph_gpu();
+        graph_dirty_ = false;
+        dirty_ = false;
+        return;
+    }
     ensure_graph();  // host-side construction first: it needs no device
     check_device();
     upload_rows();

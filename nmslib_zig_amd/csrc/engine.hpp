@@ -96,7 +96,12 @@ struct HnswBuildParams {
     int threads = 0;  // 0 = hardware concurrency
     double mult = 0;  // 0 = 1/ln(M)
     bool skip_optimized = false;
+    int gpu_build = -1;       // engine extension: 1 = batched construction on the GPU, 0 = host, -1 = auto
+    int gpu_build_batch = 0;  // max nodes inserted per batch (0 = default)
 };
+
+void hnsw_check_params(const HnswBuildParams& bp);
+std::vector<int32_t> hnsw_random_levels(size_t n, const HnswBuildParams& bp);
 
 // Construct the graph (restates Hnsw::add / kSearchElementsWithAttemptsLevel /
 // getNeighborsByHeuristic2 / addFriendlevel, src/method/hnsw.cc:534-708, include/method/hnsw.h:
@@ -165,6 +170,9 @@ class Engine {
     void ensure_graph();
     void upload_rows();
     void build_graph();
+    bool use_gpu_build() const;
+    void build_graph_gpu();
+    void prepare_graph_rows();
     void upload_graph();
     void knn_brute(const void* d_queries, size_t nq, size_t k, int32_t* d_ids, float* d_dists,
                    int32_t* d_cnt, hipStream_t stream);
@@ -201,6 +209,8 @@ class Engine {
     // workspaces
     DevBuf ws_q_, ws_qpad_, ws_cand_, ws_cnt_, ws_ids_, ws_dists_, ws_outcnt_, ws_status_, ws_bitset_;
     DevBuf ws_ndc_, ws_hops_, ws_hops_up_, ws_pair_;
+    DevBuf wb_pts_, wb_src_, wb_starts_, wb_cand_ids_, wb_cand_d_, wb_cand_n_, wb_status_, wb_req_cnt_, wb_req_node_,
+        wb_req_dist_, wb_active_, wb_nactive_;  // construction workspaces (released after the build)
     bool have_counters_ = false;
     bool prof_ = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events_;

@@ -405,13 +405,31 @@ class Builder {
 
 }  // namespace
 
-void hnsw_build_host(int space, const void* rows, size_t n, size_t dim, const HnswBuildParams& bp,
-                     HostGraph& out) {
+void hnsw_check_params(const HnswBuildParams& bp) {
     if (bp.maxM0 > 62 || bp.maxM > 62 || bp.M < 1)
         throw EngineError(Err::IndexBuildFailed, "HNSW: M/maxM/maxM0 must be in [1, 62] on the GPU engine");
     if (bp.delaunay != 0 && bp.delaunay != 2)
         throw EngineError(Err::IndexBuildFailed, "HNSW: delaunay_type must be 0 or 2 on the GPU engine");
     if (bp.post != 0) throw EngineError(Err::IndexBuildFailed, "HNSW: post-processing (post=1,2) is not supported");
+}
+
+std::vector<int32_t> hnsw_random_levels(size_t n, const HnswBuildParams& bp) {
+    // getRandomLevel (hnsw.h:478-483): one mt19937 stream seeded with the library seed 0
+    // (init.cc:34-38), consumed in insertion order
+    const double mult = bp.mult > 0 ? bp.mult : 1.0 / std::log(1.0 * bp.M);
+    std::mt19937 gen(0);
+    std::uniform_real_distribution<float> uni(0, 1);
+    std::vector<int32_t> levels(n);
+    for (size_t i = 0; i < n; ++i) {
+        float r = -std::log(uni(gen)) * mult;
+        levels[i] = (int32_t)r;
+    }
+    return levels;
+}
+
+void hnsw_build_host(int space, const void* rows, size_t n, size_t dim, const HnswBuildParams& bp,
+                     HostGraph& out) {
+    hnsw_check_params(bp);
     DistFn dist;
     dist.space = space;
     dist.dim = dim;
@@ -428,16 +446,8 @@ void hnsw_build_host(int space, const void* rows, size_t n, size_t dim, const Hn
     } else {
         dist.f = static_cast<const float*>(rows);
     }
-    // getRandomLevel (hnsw.h:478-483): one mt19937 stream seeded with the library seed 0
-    // (init.cc:34-38), consumed in insertion order
-    const double mult = bp.mult > 0 ? bp.mult : 1.0 / std::log(1.0 * bp.M);
-    std::mt19937 gen(0);
-    std::uniform_real_distribution<float> uni(0, 1);
-    std::vector<int> levels(n);
-    for (size_t i = 0; i < n; ++i) {
-        float r = -std::log(uni(gen)) * mult;
-        levels[i] = (int)r;
-    }
+    const std::vector<int32_t> lv = hnsw_random_levels(n, bp);
+    std::vector<int> levels(lv.begin(), lv.end());
     int threads = bp.threads > 0 ? bp.threads : (int)std::thread::hardware_concurrency();
     if (threads < 1) threads = 1;
     Builder b(dist, n, bp);

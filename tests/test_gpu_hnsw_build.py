@@ -1,0 +1,112 @@
+"""-m gpu: batched HNSW construction on the GPU (index parameter gpu_build=1).
+
+The batched build is not the reference's insertion schedule (a batch is searched against the graph
+before the batch), so it is held to structural invariants of Hnsw::add / addFriendlevel and to
+search quality: recall of the GPU-built graph must be on par with the reference-order host build
+(which test_cabi_cpu.py proves equal to the reference's graph) at the same parameters."""
+import numpy as np
+import pytest
+
+import nmslib_zig_amd as nz
+from tests import refio
+from tests.gpuutil import make_index
+
+pytestmark = pytest.mark.gpu
+
+
+def graph_of(idx, tmp_path, name):
+    p = str(tmp_path / name)
+    idx.save(p, save_data=False)
+    return refio.parse_optimized_index(p)
+
+
+def check_invariants(g, M, maxM, maxM0):
+    n = g["n"]
+    l0 = g["links0"]
+    cnt = l0[:, 0]
+    assert cnt.max() <= maxM0 and cnt.min() >= (1 if n > 1 else 0)
+    cols = np.arange(1, maxM0 + 1)[None, :]
+    valid = cols <= cnt[:, None]
+    nb = l0[:, 1:]
+    assert nb[valid].min() >= 0 and nb[valid].max() < n
+    assert not (valid & (nb == np.arange(n)[:, None])).any()              # no self links
+    srt = np.sort(np.where(valid, nb, -1 - cols), axis=1)                  # distinct fillers
+    assert not (np.diff(srt, axis=1) == 0).any()                           # no duplicates
+    # upper levels
+    levels, up_off, up = g["levels"], g["up_off"], g["up_links"]
+    assert g["maxlevel"] == levels.max() and levels[g["enterpoint"]] == g["maxlevel"]
+    for i in np.nonzero(levels > 0)[0]:
+        blk = up[up_off[i]:up_off[i] + levels[i] * (maxM + 1)].reshape(levels[i], maxM + 1)
+        for l in range(levels[i]):
+            c = blk[l, 0]
+            assert 0 <= c <= maxM
+            ids = blk[l, 1:1 + c]
+            assert len(set(ids.tolist())) == c and i not in ids
+            assert (levels[ids] >= l + 1).all()                            # neighbours live on that level
+
+
+@pytest.mark.parametrize("space", ["l2", "cosinesimil", "l2sqr_sift"])
+def test_gpu_build_invariants_and_recall_small(space, tmp_path):
+    n, nq, k = 20000, 500, 10
+    if space == "l2sqr_sift":
+        X, Q = refio.s_sift_like(n, 61), refio.s_sift_like(nq, 62)
+    else:
+        X, Q = refio.s_lowrank(n, 64, 61), refio.s_lowrank(nq, 64, 62)
+    bf = make_index(space, "brute_force", X)
+    ei, ed, _ = bf.knnQueryBatch(Q, 2 * k)
+    bf.close()
+    rec = {}
+    for mode in (0, 1):
+        idx = make_index(space, "hnsw", X, M=16, efConstruction=100, gpu_build=mode,
+                         **({"indexThreadQty": 4} if mode == 0 else {}))
+        if mode == 1:
+            if space != "l2sqr_sift":      # (u8 indices are saved in the reference's non-optimized format)
+                g = graph_of(idx, tmp_path, f"g_{space}.idx")
+                check_invariants(g, 16, 16, 32)
+            assert idx.stats()["build_seconds"] > 0
+        idx.setQueryTimeParams(efSearch=64)
+        ids, ds, _ = idx.knnQueryBatch(Q, k)
+        rec[mode] = refio.recall_nmslib(ids, ei, ed, k, integer=(space == "l2sqr_sift"))
+        idx.close()
+    print("recall host/gpu build:", rec)
+    assert rec[1] >= rec[0] - 0.01, rec
+    assert space == "l2sqr_sift" or rec[1] >= 0.95, rec     # (uniform-ish u8 data is hard at ef=64 for both)
+
+
+def test_gpu_build_is_deterministic_and_reloadable(tmp_path):
+    X, Q = refio.s_lowrank(6000, 32, 71), refio.s_lowrank(64, 32, 72)
+    a = make_index("l2", "hnsw", X, M=8, efConstruction=60, gpu_build=1, gpu_build_batch=256)
+    b = make_index("l2", "hnsw", X, M=8, efConstruction=60, gpu_build=1, gpu_build_batch=256)
+    ga, gb = graph_of(a, tmp_path, "a.idx"), graph_of(b, tmp_path, "b.idx")
+    np.testing.assert_array_equal(ga["links0"], gb["links0"])
+    np.testing.assert_array_equal(ga["up_links"], gb["up_links"])
+    check_invariants(ga, 8, 8, 16)
+    ids, ds, _ = a.knnQueryBatch(Q, 10)
+    c = nz.Index.load(str(tmp_path / "a.idx"), load_data=False)
+    ids2, ds2, _ = c.knnQueryBatch(Q, 10)
+    np.testing.assert_array_equal(ids, ids2)
+    np.testing.assert_array_equal(ds, ds2)
+    for i in (a, b, c):
+        i.close()
+
+
+def test_gpu_build_tiny_and_delaunay0():
+    X = refio.s_gauss(40, 8, 81)
+    idx = make_index("l2", "hnsw", X, M=4, efConstruction=20, gpu_build=1)
+    idx.setQueryTimeParams(efSearch=40)
+    ids, ds, cnt = idx.knnQueryBatch(X, 1)
+    assert (ids[:, 0] == np.arange(40)).all() and (cnt == 1).all()
+    idx.close()
+    one = make_index("l2", "hnsw", X[:1], M=4, efConstruction=20, gpu_build=1)
+    ids, ds, cnt = one.knnQueryBatch(X[:3], 5)
+    assert (cnt == 1).all() and (ids[:, 0] == 0).all()
+    one.close()
+    X, Q = refio.s_lowrank(5000, 32, 82), refio.s_lowrank(100, 32, 83)
+    bf = make_index("l2", "brute_force", X)
+    ei, ed, _ = bf.knnQueryBatch(Q, 20)
+    bf.close()
+    idx = make_index("l2", "hnsw", X, M=12, efConstruction=80, delaunay_type=0, gpu_build=1)
+    idx.setQueryTimeParams(efSearch=80)
+    ids, _, _ = idx.knnQueryBatch(Q, 10)
+    assert refio.recall_nmslib(ids, ei, ed, 10) >= 0.9
+    idx.close()
