@@ -18,6 +18,7 @@
 // that query is a lane-local register and the epilogue is one compare per element.
 // Survivors are appended to a per-(query, split) buffer in HBM (L2-resident); when a buffer
 // nears capacity the owning wave sorts it in LDS, keeps k', and raises the threshold.
+#include <cstdio>
 #include <cstdlib>
 
 #include "common.cuh"
@@ -34,6 +35,8 @@ struct BfArgs {
     u64* cand;
     int* cand_cnt;
     uint32_t* gthr;  // [qpad] best published threshold per query (order-preserving uint, 0 = none)
+    uint32_t* gq;    // [qpad][nsplit] counted bounds: 2*xj rows of that split score >= the value (0 = none)
+    int xj, xm;      // counted-bound exchange: per-lane rank published / rank taken over the splits (xj = 0: off)
     int n, ldb, nqt, nsplit, rows_per_split, kprime, cap;
     int kcs;      // floats staged per K-chunk = min(ldb, 128)
     int nchunks;  // ceil(ldb / 128)
@@ -159,6 +162,48 @@ __device__ __forceinline__ uint32_t compact_queries(u64* gbase /* query 0 of thi
     return my_thr;
 }
 
+// Counted bound shared by the row splits of one query.  Every split publishes a score v_s such
+// that at least 2*xj of ITS rows score >= v_s (the xj-th best seen by each of the query's two
+// lanes).  If T is the xm-th largest published value, 2*xj*xm >= k' rows of the whole base score
+// >= T, so the global k'-th best is >= T and every row scoring below T can be dropped -- a bound
+// of global quality (pass probability ~ k'/rows seen by ALL splits) where a split's own k'-th
+// best only gives k'/rows seen by THAT split.  Values only grow, so a stale read just prunes less;
+// loads/stores are agent-scope because the splits of a query run on different XCDs (own L2s).
+// Both lanes of a query call this; each scans half of the splits, then the two top lists merge.
+__device__ __forceinline__ uint32_t counted_bound(uint32_t* row, int nsplit, int split, int h, uint32_t pu,
+                                                  int xm) {
+    if (h == 0) __hip_atomic_store(row + split, pu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t tm[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) tm[i] = 0u;
+    auto ins = [&](uint32_t v) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const uint32_t hi = tm[i] > v ? tm[i] : v;
+            v = tm[i] > v ? v : tm[i];
+            tm[i] = hi;
+        }
+    };
+    const int per = nsplit >> 2;  // 64-bit words per lane (nsplit is a multiple of 8)
+    const u64* r64 = reinterpret_cast<const u64*>(row) + h * per;
+    for (int i = 0; i < per; ++i) {
+        const u64 w = __hip_atomic_load(r64 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int s0 = 2 * (h * per + i);
+        // own slot: the value in the register (the store above may not be visible yet, and must not count twice)
+        ins(s0 == split ? pu : (uint32_t)w);
+        ins(s0 + 1 == split ? pu : (uint32_t)(w >> 32));
+    }
+    uint32_t o[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = __shfl_xor(tm[i], 32, 64);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ins(o[i]);
+    uint32_t t = tm[0];
+#pragma unroll
+    for (int i = 1; i < 8; ++i) t = (i == xm - 1) ? tm[i] : t;
+    return t;
+}
+
 // FULL: every staged K-chunk holds exactly 128 floats (ldb % 128 == 0): the MFMA loop is
 // branch-free.  ONE: the whole row is one chunk (ldb == 128): the query fragments are loaded
 // once, outside the row loop.
@@ -168,10 +213,14 @@ __device__ __forceinline__ uint32_t compact_queries(u64* gbase /* query 0 of thi
 // rare append) is issued between those MFMAs, two elements per 8-MFMA group.  A 32x32x2 f32
 // MFMA keeps the matrix pipe busy for 64 cycles but the issue port for only a few, so the
 // epilogue's VALU/SALU work rides in the MFMA shadow instead of idling the pipe.
+__device__ long long g_bf_clk[2];  // NMSLIB_GPU_DEBUG & 1024: shader cycles / 100 MHz ticks of block 0
+__device__ long long g_bf_trace[2048][3];  // ... and per block: start tick, end tick, HW_ID
+
 template <int MODE, bool FULL, bool ONE>
 __global__ __launch_bounds__(256, 2) void bf_select_f32_kernel(BfArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long long clk_c0 = __builtin_readcyclecounter(), clk_r0 = wall_clock64();
     const int h = lane >> 5, l31 = lane & 31;
 
     // XCD-aware mapping: blocks b and b+8 share an XCD (round-robin dispatch), so the
@@ -205,6 +254,7 @@ __global__ __launch_bounds__(256, 2) void bf_select_f32_kernel(BfArgs a) {
     // bests), so that minimum never exceeds the query's k'-th best score: a threshold that
     // tightens continuously with no memory traffic and no compaction.
     const bool use_top8 = a.kprime <= 16;
+    const bool track8 = use_top8 || a.xj > 0;  // the counted-bound exchange publishes t8[xj-1]
     float t8[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) t8[i] = -INFINITY;
@@ -254,6 +304,16 @@ __global__ __launch_bounds__(256, 2) void bf_select_f32_kernel(BfArgs a) {
         if (kAux && kc == 0 && tid < BF_BN) auxs[(stage % 3) * BF_BN + tid] = stg_aux;
     };
 
+    // one eighth of write_lds (rows sr + 8*i): issued between MFMA groups so that the staging of the
+    // next tile costs no MFMA-free phase at the end of the stage
+    auto write_lds_piece = [&](int step, int i) __attribute__((always_inline)) {
+        float* t = tile + (step & 1) * BF_BN * lds_stride;
+        if (sc * 4 < kcs) *reinterpret_cast<f32x4*>(t + (sr + 8 * i) * lds_stride + sc * 4) = stg[i];
+    };
+    auto write_lds_aux = [&](int step) __attribute__((always_inline)) {
+        const int stage = step / nchunks, kc = step - stage * nchunks;
+        if (kAux && kc == 0 && tid < BF_BN) auxs[(stage % 3) * BF_BN + tid] = stg_aux;
+    };
     // query fragments: lane (l31, h) holds dims 8t + 4h + {0..3} of its query, t = 0..15
     f32x4 bq[16];
     auto load_queries = [&](int kc) __attribute__((always_inline)) {
@@ -320,7 +380,7 @@ __global__ __launch_bounds__(256, 2) void bf_select_f32_kernel(BfArgs a) {
                 npend = 1;
             }
             mycnt++;
-            if (use_top8 && s > t8[7]) {
+            if (track8 && s > t8[7]) {
                 float v = s;  // sorted insert, best first
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
@@ -394,31 +454,56 @@ __global__ __launch_bounds__(256, 2) void bf_select_f32_kernel(BfArgs a) {
         }
     };
 
+    auto exchange_counted = [&]() __attribute__((always_inline)) {
+        float mine = t8[0];
+#pragma unroll
+        for (int i = 1; i < 8; ++i) mine = (i == a.xj - 1) ? t8[i] : mine;
+        const float pv = fminf(mine, __shfl_xor(mine, 32, 64));
+        const uint32_t pu = pv > -INFINITY ? f32_ord(pv) : 0u;
+        const uint32_t t = counted_bound(a.gq + (size_t)qidx * a.nsplit, a.nsplit, split, h, pu, a.xm);
+        if (t > 1u) thr = fmaxf(thr, ord_f32(t - 1u));
+    };
+
     // ---- one 32-row block of the staged tile: 64 MFMAs into n; behind the first of them, the 16
     //      scores of the previously finished block o ----
-    auto block_mfma = [&](f32x16& n, const float* ap, int kc_len, bool epi, const f32x16& o, int o_blk, int o_stage) __attribute__((always_inline)) {
-        // fragment reads run one 8-float group ahead of the MFMAs that consume them; the first
-        // group is peeled so that the (large, rarely taken) score check sits outside the unrolled loop
-        f32x4 av = *reinterpret_cast<const f32x4*>(ap);
-        f32x4 pv = av;
-        if (8 < kc_len) pv = *reinterpret_cast<const f32x4*>(ap + 8);
-        n = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0], bq[0][0], n, 0, 0, 0);
-        n = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1], bq[0][1], n, 0, 0, 0);
-        n = __builtin_amdgcn_mfma_f32_32x32x2f32(av[2], bq[0][2], n, 0, 0, 0);
-        n = __builtin_amdgcn_mfma_f32_32x32x2f32(av[3], bq[0][3], n, 0, 0, 0);
+    auto block_mfma = [&](f32x16& n, const float* ap, const float* next_ap, f32x4& f0, f32x4& f1, int kc_len, bool epi, const f32x16& o, int o_blk, int o_stage, int wr_step) __attribute__((always_inline)) {
+        // Fragment reads run TWO 8-float groups (8 MFMAs) ahead of their use: with eight waves per CU
+        // reading 1 KB each, one group of slack does not cover the LDS latency.  f0/f1 = fragments 0/1 of
+        // this block, requested by the caller; on return they hold fragments 0/1 of the block at next_ap.
+        // The first group is peeled so that the (large, rarely taken) score check sits outside the unrolled loop.
+        f32x4 c1 = f1, c2 = f1;
+        if (16 < kc_len) c2 = *reinterpret_cast<const f32x4*>(ap + 16);
+        __builtin_amdgcn_sched_barrier(0);
+        n = __builtin_amdgcn_mfma_f32_32x32x2f32(f0[0], bq[0][0], n, 0, 0, 0);
+        n = __builtin_amdgcn_mfma_f32_32x32x2f32(f0[1], bq[0][1], n, 0, 0, 0);
+        n = __builtin_amdgcn_mfma_f32_32x32x2f32(f0[2], bq[0][2], n, 0, 0, 0);
+        n = __builtin_amdgcn_mfma_f32_32x32x2f32(f0[3], bq[0][3], n, 0, 0, 0);
         if (epi) check_block(o, o_blk, o_stage);
-        av = pv;
 #pragma unroll
         for (int tt = 1; tt < 16; ++tt) {
-            if (tt + 1 < 16 && 8 * (tt + 1) < kc_len) pv = *reinterpret_cast<const f32x4*>(ap + 8 * (tt + 1));
-            if (8 * tt < kc_len) {
-                n = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0], bq[tt][0], n, 0, 0, 0);
-                n = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1], bq[tt][1], n, 0, 0, 0);
-                n = __builtin_amdgcn_mfma_f32_32x32x2f32(av[2], bq[tt][2], n, 0, 0, 0);
-                n = __builtin_amdgcn_mfma_f32_32x32x2f32(av[3], bq[tt][3], n, 0, 0, 0);
+            f32x4 c3 = c2;
+            if (tt + 2 < 16) {
+                if (8 * (tt + 2) < kc_len) c3 = *reinterpret_cast<const f32x4*>(ap + 8 * (tt + 2));
+            } else if (next_ap) {
+                c3 = *reinterpret_cast<const f32x4*>(next_ap + 8 * (tt + 2 - 16));
             }
-            av = pv;
+            // keep the read ABOVE the MFMAs of this group: the machine scheduler otherwise sinks it next
+            // to its first use (register pressure heuristic) and exposes the whole LDS latency
+            __builtin_amdgcn_sched_barrier(0);
+            if (8 * tt < kc_len) {
+                n = __builtin_amdgcn_mfma_f32_32x32x2f32(c1[0], bq[tt][0], n, 0, 0, 0);
+                n = __builtin_amdgcn_mfma_f32_32x32x2f32(c1[1], bq[tt][1], n, 0, 0, 0);
+                n = __builtin_amdgcn_mfma_f32_32x32x2f32(c1[2], bq[tt][2], n, 0, 0, 0);
+                n = __builtin_amdgcn_mfma_f32_32x32x2f32(c1[3], bq[tt][3], n, 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (FULL && wr_step >= 0 && (tt & 1)) write_lds_piece(wr_step, tt >> 1);
+            c1 = c2;
+            c2 = c3;
         }
+        if (FULL && wr_step >= 0) write_lds_aux(wr_step);
+        f0 = c1;
+        f1 = c2;
     };
     // -0.5*||b||^2 folded in with one more MFMA: A = (aux | 0), B = (1 | 0)
     auto add_norm = [&](f32x16& n, int blk, int stage) __attribute__((always_inline)) {
@@ -497,13 +582,18 @@ __global__ __launch_bounds__(256, 2) void bf_select_f32_kernel(BfArgs a) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) accX[i] = 0.f;
             }
-            block_mfma(accX, ap0, kc_len, first && stage > 0 && !skip_epi, accY, 1, stage - 1);
+            f32x4 fr0 = *reinterpret_cast<const f32x4*>(ap0), fr1 = fr0;
+            if (8 < kc_len) fr1 = *reinterpret_cast<const f32x4*>(ap0 + 8);
+            block_mfma(accX, ap0, ap0 + 32 * lds_stride, fr0, fr1, kc_len, first && stage > 0 && !skip_epi, accY, 1,
+                       stage - 1, -1);
             if (lastc) add_norm(accX, 0, stage);
             if (first) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) accY[i] = 0.f;
             }
-            block_mfma(accY, ap0 + 32 * lds_stride, kc_len, lastc && !skip_epi, accX, 0, stage);
+            const bool stage_next = have_next && !((a.dbg & 2) && step > 0);
+            block_mfma(accY, ap0 + 32 * lds_stride, nullptr, fr0, fr1, kc_len, lastc && !skip_epi, accX, 0, stage,
+                       (FULL && stage_next) ? step + 1 : -1);
             if (lastc) add_norm(accY, 1, stage);
             if (skip_epi) asm volatile("" ::"v"(accX[0]), "v"(accY[0]), "v"(accX[15]), "v"(accY[15]));
         } else {
@@ -519,20 +609,42 @@ __global__ __launch_bounds__(256, 2) void bf_select_f32_kernel(BfArgs a) {
             if (lastc && !skip_epi) {
                 check_block(accX, 0, stage);
                 check_block(accY, 1, stage);
-                if (stage == nstages - 1) finish_stage(true);
+                if (stage == nstages - 1) {
+                    if (a.xj > 0 && !(a.dbg & (256 | 512))) exchange_counted();
+                    finish_stage(true);
+                }
             }
         }
-        if (have_next && !((a.dbg & 2) && step > 0)) write_lds(step + 1);
+        if ((!FULL || kDirect) && have_next && !((a.dbg & 2) && step > 0)) write_lds(step + 1);
         flush_pending();  // after the staging wait: these stores have a whole stage to retire
-        if (lastc && (stage & xmask) == xmask && !(a.dbg & 256)) exchange_thr();
+        if (lastc && !(a.dbg & 256)) {
+            if (a.xj > 0 && !(a.dbg & 512)) {
+                // the bound improves like 1/rows seen: exchange at stages 0,1,3,7,15,.. and every 32nd
+                if ((stage & (stage + 1)) == 0 || (stage & 31) == 31) exchange_counted();
+            } else if ((stage & xmask) == xmask) {
+                exchange_thr();
+            }
+        }
         if (!(a.dbg & 8)) __syncthreads();
     }
     // drain: block 1 of the last stage has not been examined yet; then the final compaction
     if (kDelay && nstages > 0 && !skip_epi) {
         check_block(accY, 1, nstages - 1);
+        if (a.xj > 0 && !(a.dbg & (256 | 512))) exchange_counted();
         if (!(a.dbg & 16)) finish_stage(true);
     }
     if (h == 0) a.cand_cnt[(size_t)qidx * a.nsplit + split] = mycnt;
+    if ((a.dbg & 1024) && tid == 0) {
+        if (blockIdx.x == 0) {
+            g_bf_clk[0] = __builtin_readcyclecounter() - clk_c0;
+            g_bf_clk[1] = wall_clock64() - clk_r0;
+        }
+        if (blockIdx.x < 2048) {
+            g_bf_trace[blockIdx.x][0] = clk_r0;
+            g_bf_trace[blockIdx.x][1] = wall_clock64();
+            g_bf_trace[blockIdx.x][2] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));  // HW_ID
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -876,6 +988,16 @@ BfPlan bf_make_plan(int n, int dim, int nq, int k, bool is_u8) {
     p.rows_per_split = (rps + BF_BN - 1) / BF_BN * BF_BN;
     if (p.rows_per_split < BF_BN) p.rows_per_split = BF_BN;
     p.p2max = host_next_pow2(p.nsplit * p.kprime);
+    // counted bound: xm splits x 2 lanes x xj rows >= k'; leave a quarter of the splits as slack for laggards
+    {
+        int m = (p.kprime + 1) / 2;
+        if (m > 8) m = 8;
+        if (m > p.nsplit * 3 / 4) m = p.nsplit * 3 / 4;
+        if (m < 1) m = 1;
+        const int jj = (p.kprime + 2 * m - 1) / (2 * m);
+        p.xm = m;
+        p.xj = jj <= 8 ? jj : 0;
+    }
     const int kcs = p.ldb < BF_KC ? p.ldb : BF_KC;
     if (is_u8)
         p.lds_select = 2 * BF_BN * 144 + 2 * BF_BN * 4 + BF_TQ * 4 + 4 * (size_t)p.cap * 8;
@@ -893,6 +1015,27 @@ static hipError_t launch_select_kern(const BfPlan& p, const BfArgs& a, hipStream
     if (e != hipSuccess) return e;
     const int grid = 8 * p.nqt * (p.nsplit / 8);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), p.lds_select, s, a);
+    if (a.dbg & 1024) {
+        long long h[2] = {0, 0};
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_bf_clk), sizeof(h));
+        fprintf(stderr, "[bf_select] block 0: %lld shader cycles, %.1f us, %.0f MHz\n", h[0], h[1] / 100.0,
+                h[1] ? (double)h[0] / (h[1] / 100.0) : 0.0);
+        static long long tr[2048][3];
+        (void)hipMemcpyFromSymbol(tr, HIP_SYMBOL(g_bf_trace), sizeof(tr));
+        const int nb = grid < 2048 ? grid : 2048;
+        long long t0 = tr[0][0];
+        for (int i = 0; i < nb; ++i) t0 = tr[i][0] < t0 ? tr[i][0] : t0;
+        if (getenv("NMSLIB_GPU_TRACE") && grid >= 512) {
+            FILE* f = fopen(getenv("NMSLIB_GPU_TRACE"), "w");
+            if (f) {
+                for (int i = 0; i < nb; ++i)
+                    fprintf(f, "%d %.2f %.2f %llx\n", i, (tr[i][0] - t0) / 100.0, (tr[i][1] - t0) / 100.0,
+                            (unsigned long long)tr[i][2]);
+                fclose(f);
+            }
+        }
+    }
     return hipGetLastError();
 }
 
@@ -922,6 +1065,9 @@ static BfArgs make_args(const BfPlan& p, const float* base, const float* aux, co
     a.cand = cand;
     a.cand_cnt = cnt;
     a.gthr = gthr;
+    a.gq = gthr + p.qpad;
+    a.xj = p.xj;
+    a.xm = p.xm;
     a.n = p.n;
     a.ldb = p.ldb;
     a.nqt = p.nqt;
@@ -941,7 +1087,7 @@ hipError_t launch_bf_select_f32(const BfPlan& p, int space, const float* base, c
                                 hipStream_t s) {
     // per-query shared thresholds live behind the survivor counts; cleared for every batch
     uint32_t* gthr = reinterpret_cast<uint32_t*>(cand_cnt + (size_t)p.qpad * p.nsplit);
-    hipError_t me = hipMemsetAsync(gthr, 0, (size_t)p.qpad * 4, s);
+    hipError_t me = hipMemsetAsync(gthr, 0, ((size_t)p.qpad + (size_t)p.qpad * p.nsplit) * 4, s);
     if (me != hipSuccess) return me;
     BfArgs a = make_args(p, base, aux, queries_padded, cand, cand_cnt, gthr);
     switch (space) {
@@ -957,7 +1103,7 @@ hipError_t launch_bf_select_direct_f32(const BfPlan& p, int space, const float* 
                                        const float* queries_padded, unsigned long long* cand,
                                        int* cand_cnt, hipStream_t s) {
     uint32_t* gthr = reinterpret_cast<uint32_t*>(cand_cnt + (size_t)p.qpad * p.nsplit);
-    hipError_t me = hipMemsetAsync(gthr, 0, (size_t)p.qpad * 4, s);
+    hipError_t me = hipMemsetAsync(gthr, 0, ((size_t)p.qpad + (size_t)p.qpad * p.nsplit) * 4, s);
     if (me != hipSuccess) return me;
     BfArgs a = make_args(p, base, nullptr, queries_padded, cand, cand_cnt, gthr);
     if (space == SP_L1) return launch_select_mode<BF_L1>(p, a, s);

@@ -35,13 +35,15 @@ struct BfPlan {
     int nsplit, rows_per_split;
     int kprime, cap;           // per-(query,split) survivors / candidate buffer capacity
     int p2max;                 // power of two >= nsplit*kprime (rerank sort size)
+    int xj, xm;                // counted-bound exchange between splits (bf_kernels.hip); xj = 0: off
     size_t lds_select, lds_rerank;
 };
 // Fills every field of the plan from (n, dim, nq, k).  is_u8 selects the integer path.
 BfPlan bf_make_plan(int n, int dim, int nq, int k, bool is_u8);
 inline size_t bf_cand_elems(const BfPlan& p) { return (size_t)p.qpad * p.nsplit * p.cap; }
-// per-(query,split) survivor counts, followed by the per-query shared thresholds (gthr)
-inline size_t bf_cnt_elems(const BfPlan& p) { return (size_t)p.qpad * p.nsplit + (size_t)p.qpad; }
+// per-(query,split) survivor counts, then the per-query shared thresholds (gthr), then the
+// per-(query,split) counted bounds (gq)
+inline size_t bf_cnt_elems(const BfPlan& p) { return 2 * (size_t)p.qpad * p.nsplit + (size_t)p.qpad; }
 
 // Row padding for the f32 device copy: multiple of 8 floats (two 16-byte half-wave loads).
 inline int f32_row_stride(int dim) { return (dim + 7) & ~7; }
