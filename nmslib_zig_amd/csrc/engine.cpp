@@ -224,7 +224,7 @@ size_t Engine::memory_usage() const {
 }
 
 size_t Engine::hbm_bytes() const {
-    return d_rows_.bytes() + d_aux_.bytes() + d_ids_.bytes() + d_links0_.bytes() + d_up_off_.bytes() +
+    return d_rows_.bytes() + d_rows_i8_.bytes() + d_aux_.bytes() + d_ids_.bytes() + d_links0_.bytes() + d_up_off_.bytes() +
            d_up_links_.bytes() + d_rownorm_.bytes();
 }
 
@@ -650,8 +650,12 @@ void Engine::finalize() {
     if (method_ == Method::Brute) {
         const size_t n = ids_.size();
         if (is_u8()) {
-            d_aux_.ensure(std::max<size_t>(n, 1) * 4);
-            hip_check(launch_row_aux_u8(d_rows_.as<uint8_t>(), (int)n, d_aux_.as<int32_t>(), stream_), "row aux");
+            const size_t n_pad = (size_t)bf_u8_rows_padded((int)n);
+            d_aux_.ensure(n_pad * 4);
+            d_rows_i8_.ensure(n_pad * 128);
+            hip_check(launch_prepare_u8(d_rows_.as<uint8_t>(), (int)n, d_rows_i8_.as<uint8_t>(), d_aux_.as<int32_t>(),
+                                        stream_),
+                      "prepare u8 rows");
         } else {
             d_aux_.ensure(std::max<size_t>(n, 1) * 4);
             hip_check(launch_row_aux_f32(d_rows_.as<float>(), (int)n, ldb_, (int)dim_, space_, d_aux_.as<float>(), stream_),
@@ -697,7 +701,7 @@ void Engine::knn_brute(const void* d_queries, size_t nq, size_t k, int32_t* d_id
     hip_check(launch_pad_rows(d_queries, (int)nq, dim_eff, ws_qpad_.ptr(), p.qpad, p.ldb, elem, stream), "pad queries");
     prof_begin(stream);
     if (is_u8()) {
-        hip_check(launch_bf_select_u8(p, d_rows_.as<uint8_t>(), d_aux_.as<int32_t>(), ws_qpad_.as<uint8_t>(),
+        hip_check(launch_bf_select_u8(p, d_rows_i8_.as<uint8_t>(), d_aux_.as<int32_t>(), ws_qpad_.as<uint8_t>(),
                                       ws_cand_.as<unsigned long long>(), ws_cnt_.as<int>(), stream),
                   "bf_select_u8");
     } else if (space_ == SP_L1 || space_ == SP_LINF) {

@@ -201,7 +201,7 @@ class Engine {
     // device state
     int device_ = -1;
     hipStream_t stream_ = nullptr;
-    DevBuf d_rows_, d_aux_, d_ids_, d_links0_, d_up_off_, d_up_links_, d_rownorm_;
+    DevBuf d_rows_, d_rows_i8_, d_aux_, d_ids_, d_links0_, d_up_off_, d_up_links_, d_rownorm_;
     size_t d_n_ = 0;
     int ldb_ = 0;
     HnswDeviceGraph dg_{};

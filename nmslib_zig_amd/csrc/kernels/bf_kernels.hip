@@ -432,10 +432,17 @@ __global__ __launch_bounds__(256, 2) void bf_select_f32_kernel(BfArgs a) {
         float m67 = fmaxf(fmaxf(sc[12], sc[13]), fmaxf(sc[14], sc[15]));
         const float mx = fmaxf(fmaxf(m01, m23), fmaxf(m45, m67));
         if (__any(mx > thr) && !(a.dbg & 32)) {
+            // hits are sparse: look only into the 4-row groups that hold one
+            const float m4[4] = {m01, m23, m45, m67};
 #pragma unroll
-            for (int r = 0; r < 16; ++r) consider(sc[r], row0 + acc_row(r, h), lastst);
+            for (int g = 0; g < 4; ++g) {
+                if (__any(m4[g] > thr)) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) consider(sc[4 * g + j], row0 + acc_row(4 * g + j, h), lastst);
+                }
+            }
             if (use_top8) thr = fmaxf(thr, fminf(t8[7], __shfl_xor(t8[7], 32, 64)));
-            finish_stage(false);
+            if (__any(mycnt > half - BF_BN / 2)) finish_stage(false);
         }
     };
     // Thresholds are shared between the row splits of a query through gthr (agent-scope atomic
@@ -657,13 +664,29 @@ __global__ __launch_bounds__(256, 2) void bf_select_f32_kernel(BfArgs a) {
 // positions: the survivors are exactly the (dist, position)-smallest k.
 // ---------------------------------------------------------------------------------------
 struct BfArgsU8 {
-    const uint8_t* base;   // [n][128]
-    const int32_t* aux;
+    const uint8_t* base_i8;  // [n_pad][128] re-centred copy (x ^ 0x80), n_pad = n rounded up to 64, zero rows behind n
+    const int32_t* aux;      // [n_pad], kPadAux behind n
     const uint8_t* queries;  // [qpad][128]
     u64* cand;
     int* cand_cnt;
+    uint32_t* gq;          // [qpad][nsplit] counted bounds (see counted_bound)
+    int xj, xm;
     int n, nqt, nsplit, rows_per_split, kprime, cap;
+    int dbg;
 };
+
+// Same selection machinery as the f32 kernel (block-max prefilter, pending keys, per-lane top-8,
+// counted bound between splits, wave-cooperative compaction), integer scores.
+//
+// Staging: the i8 MFMAs of a 64-row stage take only ~256 cycles per wave, far less than one
+// global-load latency, so rows are streamed by LDS-DMA (global_load_lds_dwordx4, no VGPRs) into a
+// ring of six 8 KB tiles, five stages ahead of their use; a counted vmcnt + raw s_barrier keeps four
+// tiles in flight across every barrier.  The DMA writes LDS lane-linearly (1 KiB = 8 rows x 128 B per
+// wave instruction), so the bank-conflict swizzle is applied on the SOURCE side: LDS chunk p of row r
+// holds the row's 16-byte chunk p ^ ((r >> 1) & 7).  Rows come from a copy of the base that is already
+// re-centred to int8 (x ^ 0x80) and padded to a multiple of 64 rows; aux is padded with kPadAux.
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
 
 __global__ __launch_bounds__(256, 2) void bf_select_u8_kernel(BfArgsU8 a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -675,13 +698,12 @@ __global__ __launch_bounds__(256, 2) void bf_select_u8_kernel(BfArgsU8 a) {
     const int split = (rest / a.nqt) * 8 + xcd;
     if (split >= a.nsplit) return;
 
-    constexpr int LDS_STRIDE = 144;  // 128 B row + 16 B pad (conflict-free b128 reads)
-    uint8_t* tile = reinterpret_cast<uint8_t*>(smem);                       // [2][BN][144]
-    int* auxs = reinterpret_cast<int*>(tile + 2 * BF_BN * LDS_STRIDE);      // [2][BN]
-    int* cnt = auxs + 2 * BF_BN;                                            // [TQ]
-    u64* scratch = reinterpret_cast<u64*>(cnt + BF_TQ) + (size_t)wave * a.cap;
+    constexpr int kRing = 6, kAuxRing = 8, kTileBytes = BF_BN * 128;
+    constexpr int kThr0 = -(1 << 29);     // below every real score (|score| < 2^25); pad rows score ~ -2^30
+    char* ring = smem;                                                      // [kRing][BN][128] swizzled
+    int* auxr = reinterpret_cast<int*>(ring + kRing * kTileBytes);          // [kAuxRing][BN]
+    u64* scratch = reinterpret_cast<u64*>(auxr + kAuxRing * BF_BN) + (size_t)wave * a.cap;
 
-    (void)cnt;
     const int qidx = qt * BF_TQ + wave * 32 + l31;
     const int half = a.cap >> 1;
     u64* candq = a.cand + ((size_t)qidx * a.nsplit + split) * a.cap + (size_t)h * half;
@@ -693,27 +715,22 @@ __global__ __launch_bounds__(256, 2) void bf_select_u8_kernel(BfArgsU8 a) {
     const int r_end = min(a.n, r_begin + a.rows_per_split);
     const int nstages = r_end > r_begin ? (r_end - r_begin + BF_BN - 1) / BF_BN : 0;
 
-    // staging: 64 rows x 128 B = 512 x 16 B -> 2 per thread; 8 threads per row
-    const int sc = tid & 7, sr = tid >> 3;  // sr in 0..31
-    i32x4 stg[2];
-    int stg_aux = 0;
-    auto issue_loads = [&](int stage) {
+    // one tile = 8 DMA pieces of 1 KiB (8 rows) + 64 aux words: each wave issues 2 pieces + 16 aux words
+    const int dma_row = lane >> 3;                    // row inside a piece
+    auto issue_tile = [&](int stage) __attribute__((always_inline)) {
+        const int slot = stage % kRing;
         const int row0 = r_begin + stage * BF_BN;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int row = row0 + sr + 32 * i;
-            i32x4 v = {0, 0, 0, 0};
-            if (row < r_end) v = *reinterpret_cast<const i32x4*>(a.base + (size_t)row * 128 + sc * 16);
-            stg[i] = v ^ (int)0x80808080;  // re-centre: u8 -> i8
+        for (int jj = 0; jj < 2; ++jj) {
+            const int j = 2 * wave + jj;
+            const int row = 8 * j + dma_row;
+            const int c = (lane & 7) ^ ((row >> 1) & 7);
+            const uint8_t* src = a.base_i8 + (size_t)(row0 + row) * 128 + c * 16;
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(ring + slot * kTileBytes + j * 1024), 16, 0, 0);
         }
-        if (tid < BF_BN) stg_aux = (row0 + tid < r_end) ? a.aux[row0 + tid] : 0;
-    };
-    auto write_lds = [&](int stage) {
-        uint8_t* t = tile + (stage & 1) * BF_BN * LDS_STRIDE;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-            *reinterpret_cast<i32x4*>(t + (sr + 32 * i) * LDS_STRIDE + sc * 16) = stg[i];
-        if (tid < BF_BN) auxs[(stage & 1) * BF_BN + tid] = stg_aux;
+        if (lane < 16)
+            __builtin_amdgcn_global_load_lds((gptr_t)(a.aux + row0 + 16 * wave + lane),
+                                             (lptr_t)(auxr + (stage % kAuxRing) * BF_BN + 16 * wave), 4, 0, 0);
     };
 
     // query fragments: 4 K-steps of 32 bytes; lane (l31,h) holds bytes 32*ks + 16*h + {0..15}
@@ -723,59 +740,163 @@ __global__ __launch_bounds__(256, 2) void bf_select_u8_kernel(BfArgsU8 a) {
         i32x4 v = *reinterpret_cast<const i32x4*>(a.queries + (size_t)qidx * 128 + 32 * ks + 16 * h);
         bq[ks] = v ^ (int)0x80808080;
     }
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): retire the query loads before any DMA is counted
 
-    int thr = INT32_MIN;
-    if (nstages > 0) {
-        issue_loads(0);
-        write_lds(0);
-    }
-    __syncthreads();
+    const bool use_top8 = a.kprime <= 16;
+    const bool track8 = use_top8 || a.xj > 0;
+    int t8[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t8[i] = INT32_MIN;
+    int thr = kThr0;  // pass <=> score > thr
 
-    for (int stage = 0; stage < nstages; ++stage) {
-        const bool have_next = stage + 1 < nstages;
-        if (have_next) issue_loads(stage + 1);
-        const uint8_t* t = tile + (stage & 1) * BF_BN * LDS_STRIDE;
-        i32x16 acc0, acc1;
+    u64 pend0 = 0, pend1 = 0, pend2 = 0, pend3 = 0;
+    int npend = 0;
+    auto flush_pending = [&]() __attribute__((always_inline)) {
+        const int base = mycnt - npend;
+        if (npend > 0 && base < half) candq[base] = pend0;
+        if (npend > 1 && base + 1 < half) candq[base + 1] = pend1;
+        if (npend > 2 && base + 2 < half) candq[base + 2] = pend2;
+        if (npend > 3 && base + 3 < half) candq[base + 3] = pend3;
+        npend = 0;
+    };
+    auto consider = [&](int s, int pos) __attribute__((always_inline)) {
+        if (s > thr) {
+            const u64 key = make_sel_key(i32_ord(s), (uint32_t)pos);
+            if (npend < 4) {
+                pend3 = pend2;
+                pend2 = pend1;
+                pend1 = pend0;
+                pend0 = key;
+                npend++;
+            } else {
+                flush_pending();
+                pend0 = key;
+                npend = 1;
+            }
+            mycnt++;
+            if (track8 && s > t8[7]) {
+                int v = s;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int hi = max(t8[i], v);
+                    v = min(t8[i], v);
+                    t8[i] = hi;
+                }
+            }
+        }
+    };
+    auto finish_stage = [&](bool lastst) __attribute__((always_inline)) {
+        const bool need = lastst || (mycnt > half - BF_BN / 2);
+        if (__any(need)) flush_pending();
+        if (lastst) {
+            // final pass, every lane on its own half-buffer: drop what the final threshold rules out
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            const uint32_t t_ord = i32_ord(thr);
+            const int n = mycnt < half ? mycnt : half;
+            int w = 0;
+            for (int i = 0; i < n; ++i) {
+                const u64 k0 = candq[i];
+                if ((uint32_t)(k0 >> 32) >= t_ord) candq[w++] = k0;  // ties stay: the compaction decides
+            }
+            mycnt = w;
+        }
+        const uint32_t t_ord = compact_queries(wave_cand, qstride, a.cap, a.kprime, scratch, need, mycnt, lane);
+        if (t_ord != 0u) thr = max(thr, ord_i32(t_ord));
+    };
+    auto check_block = [&](const i32x16& acc, int blk, int stage) __attribute__((always_inline)) {
+        const int* ax = auxr + (stage % kAuxRing) * BF_BN + blk * 32 + 4 * h;
+        const int row0 = r_begin + stage * BF_BN + blk * 32;
+        int sc[16];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            // rows 8g+4h+{0..3} of this block: one 16-byte read of their aux values
+            const i32x4 av = *reinterpret_cast<const i32x4*>(ax + 8 * g);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sc[4 * g + j] = 2 * acc[4 * g + j] + av[j];
+        }
+        int m4[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) m4[g] = max(max(sc[4 * g], sc[4 * g + 1]), max(sc[4 * g + 2], sc[4 * g + 3]));
+        const int mx = max(max(m4[0], m4[1]), max(m4[2], m4[3]));
+        if (__any(mx > thr) && !(a.dbg & 32)) {
+            // hits are sparse: look only into the 4-row groups that hold one
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                if (__any(m4[g] > thr)) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) consider(sc[4 * g + j], row0 + acc_row(4 * g + j, h));
+                }
+            }
+            // 16 rows of this split score >= min of the two lanes' 8th best; later rows tie-break behind them
+            if (use_top8) thr = max(thr, min(t8[7], __shfl_xor(t8[7], 32, 64)));
+            if (__any(mycnt > half - BF_BN / 2)) finish_stage(false);
+        }
+    };
+    auto exchange_counted = [&]() __attribute__((always_inline)) {
+        int mine = t8[0];
+#pragma unroll
+        for (int i = 1; i < 8; ++i) mine = (i == a.xj - 1) ? t8[i] : mine;
+        const int pv = min(mine, __shfl_xor(mine, 32, 64));
+        const uint32_t pu = i32_ord(pv);  // INT32_MIN -> 0 = nothing to report yet
+        const uint32_t t = counted_bound(a.gq + (size_t)qidx * a.nsplit, a.nsplit, split, h, pu, a.xm);
+        // rows of OTHER splits that tie with the bound may precede ours: keep score >= bound
+        if (t > 1u) thr = max(thr, ord_i32(t) - 1);
+    };
+
+    for (int t = 0; t < kRing - 1 && t < nstages; ++t) issue_tile(t);
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+
+    // Software pipeline over the stages: the fragment reads of tile t are issued first, their LDS latency
+    // is covered by the selection epilogue of tile t-1 (whose scores sit in acc0/acc1), then the MFMAs of
+    // tile t overwrite the accumulators; their latency is covered by the barrier and the next reads.
+    const int sw = (l31 >> 1) & 7;  // fragment reads undo the source-side swizzle
+    i32x16 acc0, acc1;
+    for (int t = 0; t <= nstages; ++t) {
+        const bool compute = t < nstages;
+        i32x4 fa[4], fb[4];
+        if (compute) {
+            const char* tp = ring + (t % kRing) * kTileBytes + l31 * 128;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int off = ((2 * ks + h) ^ sw) * 16;
+                fa[ks] = *reinterpret_cast<const i32x4*>(tp + off);
+                fb[ks] = *reinterpret_cast<const i32x4*>(tp + 32 * 128 + off);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);  // keep the reads above the epilogue
+        if (t > 0 && !(a.dbg & 1)) {
+            check_block(acc0, 0, t - 1);
+            check_block(acc1, 1, t - 1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (!compute) break;
+        const bool more = t + kRing - 1 < nstages;
+        // the slot of tile t+5 held tile t-1: every wave finished reading its rows before the last barrier
+        // (its aux words live in a deeper ring: other waves may still be selecting on tile t-1)
+        if (more && !(a.dbg & 2)) issue_tile(t + kRing - 1);
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             acc0[i] = 0;
             acc1[i] = 0;
         }
-        const uint8_t* ap0 = t + l31 * LDS_STRIDE + 16 * h;
-        const uint8_t* ap1 = ap0 + 32 * LDS_STRIDE;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            const i32x4 a0 = *reinterpret_cast<const i32x4*>(ap0 + 32 * ks);
-            const i32x4 a1 = *reinterpret_cast<const i32x4*>(ap1 + 32 * ks);
-            acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, bq[ks], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, bq[ks], acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[ks], bq[ks], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(fb[ks], bq[ks], acc1, 0, 0, 0);
         }
-        const int* ax = auxs + (stage & 1) * BF_BN;
-        const int row0 = r_begin + stage * BF_BN;
-        const bool last = stage == nstages - 1;
-#pragma unroll
-        for (int blk = 0; blk < 2; ++blk) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                // rows 8g+4h+{0..3} of this block: one 16-byte read of their aux values
-                const i32x4 av = *reinterpret_cast<const i32x4*>(ax + blk * 32 + 8 * g + 4 * h);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int r = 4 * g + j;
-                    const int s = 2 * (blk == 0 ? acc0[r] : acc1[r]) + av[j];
-                    const int pos = row0 + blk * 32 + 8 * g + 4 * h + j;
-                    if (s > thr && (!last || pos < r_end)) {
-                        if (mycnt < half) candq[mycnt] = make_sel_key(i32_ord(s), (uint32_t)pos);
-                        mycnt++;
-                    }
-                }
-            }
-        }
-        const bool need = last || (mycnt > half - BF_BN / 2);
-        const uint32_t t_ord = compact_queries(wave_cand, qstride, a.cap, a.kprime, scratch, need, mycnt, lane);
-        if (t_ord != 0u) thr = max(thr, ord_i32(t_ord));
-        if (have_next) write_lds(stage + 1);
-        __syncthreads();
+        if (a.dbg & 1) asm volatile("" ::"v"(acc0[0]), "v"(acc1[0]), "v"(acc0[15]), "v"(acc1[15]));
+        flush_pending();
+        if (a.xj > 0 && !(a.dbg & 256) && t > 0 && (((t - 1) & t) == 0 || ((t - 1) & 31) == 31)) exchange_counted();
+        // tile t+1 must have landed; tiles t+2 .. t+5 (3 DMA instructions each) stay in flight.
+        // Younger stores/loads of the epilogue only make this wait more conservative (in-order return).
+        if (a.dbg & 8) continue;
+        if (more) asm volatile("s_waitcnt vmcnt(12)\n\ts_barrier" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    if (nstages > 0 && !(a.dbg & 1)) {
+        if (a.xj > 0 && !(a.dbg & 256)) exchange_counted();
+        finish_stage(true);
     }
     if (h == 0) a.cand_cnt[(size_t)qidx * a.nsplit + split] = mycnt;
 }
@@ -878,12 +999,20 @@ __global__ void row_aux_f32_kernel(const float* base, int n, int ldb, int dim, i
     }
 }
 
-__global__ void row_aux_u8_kernel(const uint8_t* base, int n, int32_t* aux) {
+// aux[row] = 256*sum(a) - sum(a^2), rows_i8[row] = a ^ 0x80; rows n..n_pad-1: zero bytes, aux = kPadAux
+__global__ void prepare_u8_kernel(const uint8_t* base, int n, int n_pad, uint8_t* rows_i8, int32_t* aux) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (row >= n) return;
+    if (row >= n_pad) return;
+    uint16_t* dst = reinterpret_cast<uint16_t*>(rows_i8 + (size_t)row * 128);
+    if (row >= n) {
+        dst[lane] = 0;
+        if (lane == 0) aux[row] = -(1 << 30);
+        return;
+    }
     const uint8_t* p = base + (size_t)row * 128;
     const int x0 = p[2 * lane], x1 = p[2 * lane + 1];
+    dst[lane] = (uint16_t)((x0 | (x1 << 8)) ^ 0x8080);
     const int sum = wave_sum_i(x0 + x1);
     const int sq = wave_sum_i(x0 * x0 + x1 * x1);
     if (lane == 0) aux[row] = 256 * sum - sq;
@@ -981,6 +1110,7 @@ BfPlan bf_make_plan(int n, int dim, int nq, int k, bool is_u8) {
     int ns = want < by_rows ? want : by_rows;
     if (ns > by_sort) ns = by_sort;
     if (ns > 64) ns = 64;
+    if (const char* e = getenv("NMSLIB_GPU_SPLITS")) ns = atoi(e);  // tuning experiments
     ns = (ns + 7) / 8 * 8;
     if (ns < 8) ns = 8;
     p.nsplit = ns;
@@ -1000,7 +1130,7 @@ BfPlan bf_make_plan(int n, int dim, int nq, int k, bool is_u8) {
     }
     const int kcs = p.ldb < BF_KC ? p.ldb : BF_KC;
     if (is_u8)
-        p.lds_select = 2 * BF_BN * 144 + 2 * BF_BN * 4 + BF_TQ * 4 + 4 * (size_t)p.cap * 8;
+        p.lds_select = 6 * BF_BN * 128 + 8 * BF_BN * 4 + 4 * (size_t)p.cap * 8;  // DMA ring + aux ring + scratch
     else
         p.lds_select = (size_t)2 * BF_BN * (kcs + 4) * 4 + 2 * BF_BN * 4 + BF_TQ * 4 + 4 * (size_t)p.cap * 8;
     p.lds_rerank = (size_t)p.p2max * 8 + (p.nsplit + 1) * 4 + 16;
@@ -1111,11 +1241,11 @@ hipError_t launch_bf_select_direct_f32(const BfPlan& p, int space, const float* 
     return hipErrorInvalidValue;
 }
 
-hipError_t launch_bf_select_u8(const BfPlan& p, const uint8_t* base, const int32_t* aux,
+hipError_t launch_bf_select_u8(const BfPlan& p, const uint8_t* base_i8, const int32_t* aux,
                                const uint8_t* queries_padded, unsigned long long* cand, int* cand_cnt,
                                hipStream_t s) {
     BfArgsU8 a{};
-    a.base = base;
+    a.base_i8 = base_i8;
     a.aux = aux;
     a.queries = queries_padded;
     a.cand = cand;
@@ -1126,6 +1256,14 @@ hipError_t launch_bf_select_u8(const BfPlan& p, const uint8_t* base, const int32
     a.rows_per_split = p.rows_per_split;
     a.kprime = p.kprime;
     a.cap = p.cap;
+    uint32_t* gthr = reinterpret_cast<uint32_t*>(cand_cnt + (size_t)p.qpad * p.nsplit);
+    a.gq = gthr + p.qpad;
+    a.xj = p.xj;
+    a.xm = p.xm;
+    static const int dbg = getenv("NMSLIB_GPU_DEBUG") ? atoi(getenv("NMSLIB_GPU_DEBUG")) : 0;
+    a.dbg = dbg;
+    hipError_t me = hipMemsetAsync(gthr, 0, ((size_t)p.qpad + (size_t)p.qpad * p.nsplit) * 4, s);
+    if (me != hipSuccess) return me;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bf_select_u8_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_select);
     if (e != hipSuccess) return e;
@@ -1168,9 +1306,9 @@ hipError_t launch_row_aux_f32(const float* base, int n, int ldb, int dim, int sp
     hipLaunchKernelGGL(row_aux_f32_kernel, dim3((n + 3) / 4), dim3(256), 0, s, base, n, ldb, dim, space, aux);
     return hipGetLastError();
 }
-hipError_t launch_row_aux_u8(const uint8_t* base, int n, int32_t* aux, hipStream_t s) {
-    if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(row_aux_u8_kernel, dim3((n + 3) / 4), dim3(256), 0, s, base, n, aux);
+hipError_t launch_prepare_u8(const uint8_t* base, int n, uint8_t* rows_i8, int32_t* aux, hipStream_t s) {
+    const int n_pad = bf_u8_rows_padded(n);
+    hipLaunchKernelGGL(prepare_u8_kernel, dim3((n_pad + 3) / 4), dim3(256), 0, s, base, n, n_pad, rows_i8, aux);
     return hipGetLastError();
 }
 hipError_t launch_pad_rows(const void* src, int rows, int dim, void* dst, int rows_pad, int ld,

@@ -53,8 +53,10 @@ inline int f32_row_stride(int dim) { return (dim + 7) & ~7; }
 // NEGDOT -> unused (0).
 hipError_t launch_row_aux_f32(const float* base, int n, int ldb, int dim, int space, float* aux,
                               hipStream_t s);
-// u8: aux = 256*sum(a) - sum(a^2)   (see bf_select_u8)
-hipError_t launch_row_aux_u8(const uint8_t* base, int n, int32_t* aux, hipStream_t s);
+// u8 brute force: rows_i8 [n_pad][128] = re-centred copy (x ^ 0x80), aux [n_pad] = 256*sum(a) - sum(a^2);
+// n_pad = bf_u8_rows_padded(n), pad rows are zero with an aux that can never be selected (see bf_select_u8)
+inline int bf_u8_rows_padded(int n) { return (n + BF_BN - 1) / BF_BN * BF_BN + BF_BN; }
+hipError_t launch_prepare_u8(const uint8_t* base, int n, uint8_t* rows_i8, int32_t* aux, hipStream_t s);
 // Copy [rows][dim] -> [rows_pad][ld] with zero fill (elem = 4 or 1 bytes).
 hipError_t launch_pad_rows(const void* src, int rows, int dim, void* dst, int rows_pad, int ld,
                            int elem_bytes, hipStream_t s);
@@ -65,7 +67,7 @@ hipError_t launch_normalize_rows(float* rows, int n, int ld, int dim, hipStream_
 hipError_t launch_bf_select_f32(const BfPlan& p, int space, const float* base, const float* aux,
                                 const float* queries_padded, unsigned long long* cand,
                                 int* cand_cnt, hipStream_t s);
-hipError_t launch_bf_select_u8(const BfPlan& p, const uint8_t* base, const int32_t* aux,
+hipError_t launch_bf_select_u8(const BfPlan& p, const uint8_t* base_i8, const int32_t* aux,
                                const uint8_t* queries_padded, unsigned long long* cand,
                                int* cand_cnt, hipStream_t s);
 // Direct (VALU) selection for spaces with no inner-product form (l1, linf).
