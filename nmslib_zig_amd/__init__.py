@@ -307,6 +307,25 @@ class Index:
         _check(L.nmslib_knn_query_fill(self.h, q.ctypes.data, q.shape[0], k, C.byref(r), 0), self.alloc)
         return ids[:r.size].copy(), ds[:r.size].copy()
 
+    def rangeQuery(self, query, radius):
+        """lib.zig:933-965: get_size (an estimate, 128) sizes the buffers, fill writes the first `capacity`
+        objects within the radius, in insertion order.  HNSW -> NmslibError(SPACE_INCOMPATIBLE)."""
+        L = lib()
+        q = np.ascontiguousarray(query, np.uint8 if self.data_type == "DenseUInt8Vector" else np.float32)
+        L.nmslib_initialize_pool(self.h)
+        cap = C.c_size_t()
+        _check(L.nmslib_range_query_get_size(self.h, q.ctypes.data, q.shape[0], float(radius), C.byref(cap), 0), self.alloc)
+        return self.rangeQueryFill(q, radius, cap.value)
+
+    def rangeQueryFill(self, query, radius, capacity):
+        L = lib()
+        q = np.ascontiguousarray(query, np.uint8 if self.data_type == "DenseUInt8Vector" else np.float32)
+        ids = np.empty(capacity, np.int32)
+        ds = np.empty(capacity, np.float32)
+        r = Result(ids.ctypes.data_as(C.POINTER(C.c_int32)), ds.ctypes.data_as(C.POINTER(C.c_float)), 0, capacity)
+        _check(L.nmslib_range_query_fill(self.h, q.ctypes.data, q.shape[0], float(radius), C.byref(r), 0), self.alloc)
+        return ids[:r.size].copy(), ds[:r.size].copy()
+
     def knnQueryBatch(self, queries, k):
         """One call of nmslib_knn_query_batch: a single GPU batch.  -> ids [Q,k], dists [Q,k], counts [Q]"""
         L = lib()

@@ -402,8 +402,6 @@ nmslib_error_t nmslib_range_query_get_size(nmslib_index_handle_t index, const vo
 nmslib_error_t nmslib_range_query_fill(nmslib_index_handle_t index, const void* query,
                                        size_t query_size_or_elem_count, double radius, nmslib_result_t* result,
                                        size_t num_elements) {
-    (void)query_size_or_elem_count;
-    (void)radius;
     (void)num_elements;
     if (!index || !query || !result || result->capacity == 0) FAIL(NMSLIB_ERROR_INVALID_ARGUMENT, "Invalid range fill inputs");
     Engine* e = H(index)->engine;
@@ -411,7 +409,19 @@ nmslib_error_t nmslib_range_query_fill(nmslib_index_handle_t index, const void* 
     result->size = 0;
     if (e->method_name() == "hnsw")  // Hnsw::Search(RangeQuery*) throws (hnsw.cc:710-715) -> nmslib_c.cpp:1131-1141
         FAIL(NMSLIB_ERROR_SPACE_INCOMPATIBLE, "Range query not supported by method: Range search is not supported!");
-    FAIL(NMSLIB_ERROR_RUNTIME, "Range query exception: range search is not implemented in the GPU engine yet");
+    try {
+        std::lock_guard<std::mutex> lk(e->mu);
+        result->size = e->range_host(query, query_size_or_elem_count, radius, result->capacity, result->ids,
+                                     result->distances);
+    } catch (const EngineError& ex) {
+        FAIL(static_cast<nmslib_error_t>(ex.code), std::string("Range query exception: ") + ex.what());
+    } catch (const std::bad_alloc& ex) {
+        FAIL(NMSLIB_ERROR_OUT_OF_MEMORY, std::string("Range query alloc failed: ") + ex.what());
+    } catch (const std::exception& ex) {
+        FAIL(NMSLIB_ERROR_RUNTIME, std::string("Range query exception: ") + ex.what());
+    }
+    SET_LAST(NMSLIB_SUCCESS, "Range query filled successfully");
+    return NMSLIB_SUCCESS;
 }
 
 // ---- stored data -------------------------------------------------------------------------------

@@ -790,6 +790,43 @@ void Engine::knn_host(const void* queries, size_t nq, size_t elem_count, size_t 
     hip_check(hipStreamSynchronize(stream_), "knn");
 }
 
+size_t Engine::range_host(const void* query, size_t elem_count, double radius, size_t capacity, int32_t* ids,
+                          float* dists) {
+    if (!created_) throw EngineError(Err::IndexBuildFailed, "Index not built");
+    if (dirty_) finalize();
+    check_device();
+    const size_t n = d_n_;
+    if (n == 0 || capacity == 0) return 0;
+    if (elem_count != dim_) throw EngineError(Err::QueryExecutionFailed, "query dimension does not match the index");
+    // RangeQuery<dist_t>(space, obj, static_cast<dist_t>(radius)), nmslib_c.cpp:1092-1093
+    const float r = is_u8() ? (float)(int)radius : (float)radius;
+    const int ld = is_u8() ? 128 : ldb_;
+    const int elem = is_u8() ? 1 : 4;
+    ws_qpad_.ensure((size_t)ld * elem);
+    ws_q_.ensure(elem_count * elem);
+    ws_rdist_.ensure(n * 4);
+    ws_rcnt_.ensure(range_count_elems((int)n) * 4);
+    ws_ids_.ensure(capacity * 4);
+    ws_dists_.ensure(capacity * 4);
+    hip_check(hipMemcpyAsync(ws_q_.ptr(), query, elem_count * elem, hipMemcpyHostToDevice, stream_), "query H2D");
+    hip_check(launch_pad_rows(ws_q_.ptr(), 1, (int)dim_, ws_qpad_.ptr(), 1, ld, elem, stream_), "pad query");
+    hip_check(launch_range_search(space_, d_rows_.ptr(), ld, (int)n, ws_qpad_.ptr(), (int)dim_, r, d_ids_.as<int32_t>(),
+                                  ws_rdist_.as<float>(), ws_rcnt_.as<int>(), (int)std::min<size_t>(capacity, INT32_MAX),
+                                  ws_ids_.as<int32_t>(), ws_dists_.as<float>(), stream_),
+              "range search");
+    int total = 0;
+    hip_check(hipMemcpyAsync(&total, ws_rcnt_.as<int>() + (range_count_elems((int)n) - 1), 4, hipMemcpyDeviceToHost, stream_),
+              "range count");
+    hip_check(hipStreamSynchronize(stream_), "range search");
+    const size_t m = std::min<size_t>((size_t)total, capacity);
+    if (m) {
+        hip_check(hipMemcpyAsync(ids, ws_ids_.ptr(), m * 4, hipMemcpyDeviceToHost, stream_), "range ids");
+        hip_check(hipMemcpyAsync(dists, ws_dists_.ptr(), m * 4, hipMemcpyDeviceToHost, stream_), "range dists");
+        hip_check(hipStreamSynchronize(stream_), "range search");
+    }
+    return m;
+}
+
 float Engine::pair_distance(size_t p1, size_t p2) {
     // Space::IndexTimeDistance on the ORIGINAL rows (nmslib_c.cpp:1166), one wave on the GPU
     check_device();

@@ -144,6 +144,9 @@ class Engine {
     void knn_host(const void* queries, size_t nq, size_t elem_count, size_t k, std::vector<int32_t>& ids,
                   std::vector<float>& dists, std::vector<int32_t>& cnt);
     float pair_distance(size_t p1, size_t p2);
+    // RangeQuery on the brute-force index: matches in insertion order, the first `capacity`; returns how many were written
+    size_t range_host(const void* query, size_t elem_count, double radius, size_t capacity, int32_t* ids, float* dists);
+    bool is_brute() const { return method_ == Method::Brute; }
 
     void save(const std::string& path, bool save_data);
     static std::unique_ptr<Engine> load(const std::string& path, int data_type, int dist_type, bool load_data);
@@ -208,7 +211,7 @@ class Engine {
 
     // workspaces
     DevBuf ws_q_, ws_qpad_, ws_cand_, ws_cnt_, ws_ids_, ws_dists_, ws_outcnt_, ws_status_, ws_bitset_;
-    DevBuf ws_ndc_, ws_hops_, ws_hops_up_, ws_pair_;
+    DevBuf ws_ndc_, ws_hops_, ws_hops_up_, ws_pair_, ws_rdist_, ws_rcnt_;
     DevBuf wb_pts_, wb_src_, wb_starts_, wb_cand_ids_, wb_cand_d_, wb_cand_n_, wb_status_, wb_req_cnt_, wb_req_node_,
         wb_req_dist_, wb_active_, wb_nactive_;  // construction workspaces (released after the build)
     bool have_counters_ = false;

@@ -142,6 +142,14 @@ hipError_t launch_hnsw_build_link(const HnswBuildGraph& bg, int level, const int
                                   const int32_t* nactive, int max_active, int32_t* req_cnt,
                                   const int32_t* req_node, const float* req_dist, int req_cap, hipStream_t s);
 
+// ---- range search on the brute-force index (range_kernels.hip) ----------------------------------
+// dist_ws: [n] floats; count_ws: [ceil(n/1024) + 1] ints, the last one receives the number of matches.
+// Matches (distance <= radius) are written in position order, the first `capacity` of them.
+inline size_t range_count_elems(int n) { return (size_t)(n + 1023) / 1024 + 1; }
+hipError_t launch_range_search(int space, const void* rows, int ld, int n, const void* query_padded, int dim,
+                               float radius, const int32_t* ext_ids, float* dist_ws, int* count_ws, int capacity,
+                               int32_t* out_ids, float* out_dists, hipStream_t s);
+
 // ---- shard merge ---------------------------------------------------------------------------
 hipError_t launch_merge_topk(const float* dists_in, const int32_t* ids_in, int nshards, int nq,
                              int k, float* dists_out, int32_t* ids_out, hipStream_t s);

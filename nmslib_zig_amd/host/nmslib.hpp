@@ -126,6 +126,20 @@ class Index {
         r.distances.resize(c.size);
         return r;
     }
+    // lib.zig:933-965: the size estimate (128) sizes the buffers; HNSW -> Error(SPACE_INCOMPATIBLE)
+    QueryResult rangeQuery(const void* query, size_t elem_count, double radius) {
+        nmslib_initialize_pool(h_);
+        size_t cap = 0;
+        check(nmslib_range_query_get_size(h_, query, elem_count, radius, &cap, 0), alloc_, "range_query_get_size");
+        QueryResult r;
+        r.ids.resize(cap);
+        r.distances.resize(cap);
+        nmslib_result_t c{r.ids.data(), r.distances.data(), 0, cap};
+        check(nmslib_range_query_fill(h_, query, elem_count, radius, &c, 0), alloc_, "rangeQuery");
+        r.ids.resize(c.size);
+        r.distances.resize(c.size);
+        return r;
+    }
     // One GPU batch (the reference loops per query, lib.zig:889-931).
     std::vector<QueryResult> knnQueryBatch(const void* queries, size_t count, size_t elem_count, size_t k) {
         std::vector<QueryResult> out(count);

@@ -158,3 +158,50 @@ def test_full_size_properties_1M():
         for j in (1, 9):
             assert abs(idx.getDistance(int(q * 977), int(ids[q, j])) - ds[q, j]) <= 1e-5 * ds[q, j]
     idx.close()
+
+
+# ---- range queries (RangeQuery::CheckAndAddToResult, rangequery.cc:67-76) -------------
+@pytest.mark.parametrize("space", ["l2", "l1", "linf", "cosinesimil", "angulardist", "negdotprod", "l2sqr_sift"])
+def test_range_query_matches_oracle_scan(space):
+    """Everything within the radius, in insertion order, distances in the reference formula; a result
+    buffer smaller than the match count keeps the FIRST matches (nmslib_c.cpp:1104-1113)."""
+    u8 = space == "l2sqr_sift"
+    n, D = 5000, 128 if u8 else 37
+    X = refio.s_sift_like(n, 91) if u8 else refio.s_gauss(n, D, 91)
+    Q = refio.s_sift_like(3, 92) if u8 else refio.s_gauss(3, D, 92)
+    ext = (np.arange(n, dtype=np.int32) * 3 + 11)
+    idx = make_index(space, "seq_search", X, ext)
+    for q in Q:
+        want_d = np.array([orc.space_distance(space, q, x) for x in X[:n]], np.float64)
+        radius = float(np.sort(want_d)[300])            # ~300 matches
+        if u8:
+            radius = float(int(radius))
+        ids, ds = idx.rangeQueryFill(q, radius, 1000)
+        m = want_d <= np.float32(radius)
+        # float spaces: rows whose distance is within rounding of the radius may fall on either side
+        edge = np.abs(want_d - radius) <= 1e-5 * max(1.0, abs(radius)) if not u8 else np.zeros(n, bool)
+        got = set(ids.tolist())
+        assert set(ext[m & ~edge].tolist()) <= got <= set(ext[m | edge].tolist())
+        assert (np.diff(ids) > 0).all()                 # insertion order (ext ids grow with position)
+        pos = (ids - 11) // 3
+        if u8:
+            np.testing.assert_array_equal(ds, want_d[pos].astype(np.float32))
+        else:
+            assert close_rel(ds, want_d[pos], atol=1e-5)
+        # capacity smaller than the match count: the first matches in insertion order
+        ids2, ds2 = idx.rangeQueryFill(q, radius, 50)
+        np.testing.assert_array_equal(ids2, ids[:50])
+        # the lib.zig call sequence sizes its buffers with the 128 estimate
+        if radius >= 0:                                 # (negative radii -- negdotprod -- are refused by get_size)
+            ids3, _ = idx.rangeQuery(q, radius)
+            np.testing.assert_array_equal(ids3, ids[:128])
+    # radius 0 on a stored row returns at least that row; negative radius is refused
+    ids, ds = idx.rangeQueryFill(X[7], 0.0 if space not in ("negdotprod",) else float(orc.space_distance(space, X[7], X[7])), 10)
+    if space not in ("negdotprod", "cosinesimil", "angulardist"):
+        assert ext[7] in ids
+    # negative radius: get_size refuses it (nmslib_c.cpp:1038), fill just finds nothing
+    with pytest.raises(nz.NmslibError):
+        idx.rangeQuery(X[7], -1.0)
+    if space != "negdotprod":
+        assert len(idx.rangeQueryFill(X[7], -1.0, 10)[0]) == 0
+    idx.close()
