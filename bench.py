@@ -47,9 +47,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", choices=["bruteforce", "hnsw", "sift"], default="bruteforce")
+    ap.add_argument("--workload", choices=["bruteforce", "hnsw", "sift", "cos768"], default="bruteforce")
     ap.add_argument("--n", type=int, default=1_000_000)
-    ap.add_argument("--dim", type=int, default=128)
+    ap.add_argument("--dim", type=int, default=None)
     ap.add_argument("--batch", type=int, default=None)
     ap.add_argument("--k", type=int, default=None)
     ap.add_argument("--ef", type=int, default=128)
@@ -60,9 +60,25 @@ def parse():
     return ap.parse_args()
 
 
+def s_768(n, dim, seed, rank=64, chunk=1 << 18):
+    """S-768: rank-64 latent + 0.1 noise, rows L2-normalised; generated in chunks."""
+    A = np.random.default_rng(45).standard_normal((dim, rank)).astype(np.float32)
+    out = np.empty((n, dim), np.float32)
+    rng = np.random.default_rng(seed)
+    for lo in range(0, n, chunk):
+        hi = min(n, lo + chunk)
+        x = rng.standard_normal((hi - lo, rank), dtype=np.float32) @ A.T
+        x += 0.1 * rng.standard_normal((hi - lo, dim), dtype=np.float32)
+        x /= np.linalg.norm(x, axis=1, keepdims=True)
+        out[lo:hi] = x
+    return out
+
+
 def make_data(a):
     if a.workload == "sift":
         return refio.s_sift_like(a.n, 44), refio.s_sift_like(a.batch, 45)
+    if a.workload == "cos768":
+        return s_768(a.n, a.dim, 46), s_768(a.batch, a.dim, 47)
     return refio.s_lowrank(a.n, a.dim, 42), refio.s_lowrank(a.batch, a.dim, 43)   # SURVEY.md 8d
 
 
@@ -83,8 +99,8 @@ def cpu_baseline(a, X, Q, gt_ids, gt_d):
     query q on thread q mod T (Experiments::Execute protocol).  Bounded sample."""
     from tests import orc
     cores = host_threads()
-    space = "l2sqr_sift" if a.workload == "sift" else "l2"
-    if a.workload == "hnsw":
+    space = {"sift": "l2sqr_sift", "cos768": "cosinesimil"}.get(a.workload, "l2")
+    if a.workload in ("hnsw", "cos768"):
         method, ip, qp = "hnsw", f"M=16,efConstruction=200,indexThreadQty={cores}", f"efSearch={a.ef}"
         ns = a.cpu_sample or min(Q.shape[0], 1024)
     else:
@@ -95,7 +111,7 @@ def cpu_baseline(a, X, Q, gt_ids, gt_d):
     if refio.HAVE_REF:
         ids, d, cnt, ndc, info = refio.run_ref_driver(space, method, X, Qs, a.k, ip, qp, threads=cores, repeat=1)
         kind, qps, used = "reference", info["qps"], cores
-        extra = {"build_s": info["build_s"]} if a.workload == "hnsw" else {}
+        extra = {"build_s": info["build_s"]} if method == "hnsw" else {}
     else:
         # oracle/_ref was not shipped: time this repo's scalar restatement instead (1 thread)
         ns = min(ns, 8)
@@ -106,7 +122,7 @@ def cpu_baseline(a, X, Q, gt_ids, gt_d):
     rec = None
     if gt_ids is not None:
         m = min(ns, len(gt_ids))
-        gd = gt_d[:m] ** 2 if (a.workload == "hnsw") else gt_d[:m]
+        gd = gt_d[:m] ** 2 if (a.workload == "hnsw") else gt_d[:m]   # HNSW-l2 returns squared L2
         rec = refio.recall_nmslib(ids[:m], gt_ids[:m], gd, a.k, integer=(a.workload == "sift"))
     out = {"value": round(float(qps), 2), "unit": "queries/s", "cores": used, "kind": kind,
            "sample": f"{ns} of the {Q.shape[0]} queries against all {X.shape[0]} rows, method={method}"
@@ -123,8 +139,12 @@ def main():
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
+    if a.dim is None:
+        a.dim = 768 if a.workload == "cos768" else 128
     if a.batch is None:
-        a.batch = 4096 if a.workload == "sift" else 1024
+        a.batch = {"sift": 4096, "cos768": 8192}.get(a.workload, 1024)
+    if a.workload == "cos768":
+        a.no_cpu_baseline = a.no_cpu_baseline or a.n > 200_000   # the reference's 768-D build takes too long beyond that
     if a.k is None:
         a.k = 100 if a.workload == "sift" else 10
     torch.cuda.set_device(local % max(1, torch.cuda.device_count()))
@@ -138,8 +158,8 @@ def main():
     n, nq, k = X.shape[0], Q.shape[0], a.k
     lo, hi = rank * n // world, (rank + 1) * n // world          # this rank's row shard
     u8 = a.workload == "sift"
-    space = "l2sqr_sift" if u8 else "l2"
-    method = "hnsw" if a.workload == "hnsw" else "seq_search"
+    space = "l2sqr_sift" if u8 else ("cosinesimil" if a.workload == "cos768" else "l2")
+    method = "hnsw" if a.workload in ("hnsw", "cos768") else "seq_search"
     cache = a.index_cache if (method == "hnsw" and world == 1) else ""
     t_build = time.time()
     if cache and os.path.exists(cache):
@@ -165,12 +185,11 @@ def main():
     note(f"index ready in {t_build:.1f}s; timing {a.steps} steps")
 
     dq = torch.from_numpy(Q).to(dev)
-    d_ids = torch.empty((nq, k), dtype=torch.int32, device=dev)
-    d_ds = torch.empty((nq, k), dtype=torch.float32, device=dev)
+    pack = torch.empty((2, nq, k), dtype=torch.int32, device=dev)    # ids | distance bits: one collective moves both
+    d_ids, d_ds = pack[0], pack[1].view(torch.float32)
     d_cnt = torch.empty((nq,), dtype=torch.int32, device=dev)
     if world > 1:
-        g_ids = torch.empty((world * nq, k), dtype=torch.int32, device=dev)   # [world][nq][k], concatenated form
-        g_ds = torch.empty((world * nq, k), dtype=torch.float32, device=dev)
+        g_pack = torch.empty((world * 2, nq, k), dtype=torch.int32, device=dev)   # [world][2][nq][k], concatenated form
         m_ids = torch.empty((nq, k), dtype=torch.int32, device=dev)
         m_ds = torch.empty((nq, k), dtype=torch.float32, device=dev)
     stream = torch.cuda.current_stream()
@@ -179,10 +198,10 @@ def main():
         idx.knn_device(dq.data_ptr(), nq, Q.shape[1], k, d_ids.data_ptr(), d_ds.data_ptr(), d_cnt.data_ptr(),
                        stream.cuda_stream)
         if world > 1:
-            dist.all_gather_into_tensor(g_ds, d_ds)
-            dist.all_gather_into_tensor(g_ids, d_ids)
-            nz._check(nz.lib().nmslib_gpu_merge_topk(g_ds.data_ptr(), g_ids.data_ptr(), world, nq, k,
-                                                     m_ds.data_ptr(), m_ids.data_ptr(), stream.cuda_stream))
+            dist.all_gather_into_tensor(g_pack, pack)
+            nz._check(nz.lib().nmslib_gpu_merge_topk_strided(g_pack.data_ptr() + nq * k * 4, g_pack.data_ptr(),
+                                                             2 * nq * k, world, nq, k, m_ds.data_ptr(),
+                                                             m_ids.data_ptr(), stream.cuda_stream))
 
     def sync():
         if world > 1:
@@ -218,12 +237,15 @@ def main():
     recall = None
     if world == 1:
         if method == "hnsw":
-            bf = nz.Index("l2", "seq_search")
+            ngt = nq if a.workload == "hnsw" else min(nq, 256)
+            idx.close()                                                        # free the HBM copy first
+            bf = nz.Index(space, "seq_search")
             bf.addDenseBatch(X)
             bf.buildIndex()
-            gt_ids, gt_d, _ = bf.knnQueryBatch(Q, k + 22)
+            gt_ids, gt_d, _ = bf.knnQueryBatch(Q[:ngt], k + 22)
             bf.close()
-            recall = refio.recall_nmslib(res_ids, gt_ids, gt_d ** 2, k)       # HNSW-l2 returns squared L2
+            # HNSW-l2 returns squared L2; cosine distances are the same on both paths
+            recall = refio.recall_nmslib(res_ids[:ngt], gt_ids, gt_d ** 2 if space == "l2" else gt_d, k)
         else:
             # brute force IS the exact method; its recall against itself at k+22 checks the tie rule
             gt_ids, gt_d, _ = idx.knnQueryBatch(Q[:64], min(k + 22, 512))
@@ -254,12 +276,14 @@ def main():
     tr = os.path.join(ROOT, "profiles", "traffic.json")       # PMC-measured HBM bytes/launch, if collected
     if os.path.exists(tr):
         try:
-            roof["traffic"] = json.load(open(tr)).get(a.workload)
+            roof["traffic"] = json.load(open(tr)).get(a.workload) if a.n == 1_000_000 else None
         except Exception:
             pass
 
     out = {
-        "metric": "queries/sec @ recall@10, 1M x 128-D L2, batch=1024",
+        "metric": {"sift": f"queries/sec @ recall@{k}, {n} x 128-D u8 l2sqr_sift, batch={nq}",
+                   "cos768": f"queries/sec @ recall@{k}, {n} x {Q.shape[1]}-D cosinesimil HNSW, batch={nq}"}.get(
+                       a.workload, "queries/sec @ recall@10, 1M x 128-D L2, batch=1024"),
         "value": round(a.steps * nq / elapsed, 1),
         "unit": "queries/s",
         "n_gpus": world,
@@ -274,9 +298,13 @@ def main():
         "config": {
             "workload": {"bruteforce": "brute-force L2 1Mx128 f32 k=10 batch=1024 (BASELINE configs[1])",
                          "hnsw": f"HNSW l2 1Mx128 f32 M=16 efS={a.ef} k=10 batch=1024 (BASELINE configs[2])",
-                         "sift": "l2sqr_sift 1Mx128 u8 k=100 batch=4096 (BASELINE configs[3])"}[a.workload],
+                         "sift": "l2sqr_sift 1Mx128 u8 k=100 batch=4096 (BASELINE configs[3])",
+                         "cos768": f"HNSW cosinesimil {n}x{Q.shape[1]} f32 M=16 efS={a.ef} k=10 batch={nq} "
+                                   "(one shard of BASELINE configs[4])"}[a.workload],
             "rows": n, "dim": int(Q.shape[1]), "batch": nq, "k": k, "rows_per_gpu": rows_local,
-            "dataset": "S-sift-like seeds 44/45" if u8 else "S-lowrank rank-16 + 0.1 noise, seeds 42/43",
+            "dataset": "S-sift-like seeds 44/45" if u8 else ("S-768 rank-64 + 0.1 noise, unit rows, seeds 46/47"
+                                                             if a.workload == "cos768" else
+                                                             "S-lowrank rank-16 + 0.1 noise, seeds 42/43"),
             "sharding": f"rows/{world} + RCCL all-gather of per-shard top-k" if world > 1 else "single GPU",
             "build_s": round(t_build, 2),
         },

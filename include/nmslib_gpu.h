@@ -56,6 +56,15 @@ nmslib_error_t nmslib_gpu_merge_topk(const float* d_dists_in, const int32_t* d_i
                                      size_t nshards, size_t query_count, size_t k,
                                      float* d_dists_out, int32_t* d_ids_out, void* stream);
 
+/* Same merge for per-shard lists that are not back to back: shard s starts at d_dists_in + s*shard_stride and
+ * d_ids_in + s*shard_stride (elements).  Lets ONE all-gather move ids and distances together: every rank
+ * contributes a packed [2][query_count][k] block (ids, then the distances' bit patterns), the gathered buffer is
+ * [nshards][2][query_count][k] and shard_stride = 2*query_count*k. */
+nmslib_error_t nmslib_gpu_merge_topk_strided(const float* d_dists_in, const int32_t* d_ids_in,
+                                             size_t shard_stride, size_t nshards, size_t query_count,
+                                             size_t k, float* d_dists_out, int32_t* d_ids_out,
+                                             void* stream);
+
 /* Live timing of the dominant kernel (bf_select_* for brute force, hnsw_search for HNSW) with
  * HIP events recorded on the stream the kernel is launched on.  enable != 0 starts recording
  * (one event pair per batch); a call with total_ms / launches non-NULL waits for the recorded

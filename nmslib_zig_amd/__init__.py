@@ -130,6 +130,7 @@ def lib():
         "nmslib_gpu_knn_query_batch_device": (C.c_int, [vp, vp, sz, sz, sz, vp, vp, vp, vp]),
         "nmslib_gpu_last_batch_counters": (C.c_int, [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]),
         "nmslib_gpu_merge_topk": (C.c_int, [vp, vp, sz, sz, sz, vp, vp, vp]),
+        "nmslib_gpu_merge_topk_strided": (C.c_int, [vp, vp, sz, sz, sz, sz, vp, vp, vp]),
         "nmslib_gpu_get_stats": (C.c_int, [vp, C.POINTER(GpuStats)]),
         "nmslib_gpu_kernel_timing": (C.c_int, [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
     }
@@ -157,7 +158,7 @@ ABI_SYMBOLS_C = [  # the 37 symbols of the reference boundary
 ]
 ABI_SYMBOLS_GPU = ["nmslib_gpu_device_count", "nmslib_gpu_finalize",
                    "nmslib_gpu_knn_query_batch_device", "nmslib_gpu_last_batch_counters",
-                   "nmslib_gpu_merge_topk", "nmslib_gpu_get_stats", "nmslib_gpu_kernel_timing"]
+                   "nmslib_gpu_merge_topk", "nmslib_gpu_merge_topk_strided", "nmslib_gpu_get_stats", "nmslib_gpu_kernel_timing"]
 
 
 class TrackingAllocator:

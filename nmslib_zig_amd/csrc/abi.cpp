@@ -652,18 +652,25 @@ nmslib_error_t nmslib_gpu_last_batch_counters(nmslib_index_handle_t handle, cons
     return NMSLIB_SUCCESS;
 }
 
-nmslib_error_t nmslib_gpu_merge_topk(const float* d_dists_in, const int32_t* d_ids_in, size_t nshards,
-                                     size_t query_count, size_t k, float* d_dists_out, int32_t* d_ids_out,
-                                     void* stream) {
-    if (!d_dists_in || !d_ids_in || !d_dists_out || !d_ids_out || nshards == 0 || k == 0)
+nmslib_error_t nmslib_gpu_merge_topk_strided(const float* d_dists_in, const int32_t* d_ids_in, size_t shard_stride,
+                                             size_t nshards, size_t query_count, size_t k, float* d_dists_out,
+                                             int32_t* d_ids_out, void* stream) {
+    if (!d_dists_in || !d_ids_in || !d_dists_out || !d_ids_out || nshards == 0 || k == 0 || shard_stride < query_count * k)
         FAIL(NMSLIB_ERROR_INVALID_ARGUMENT, "Invalid merge inputs");
     if (nshards * k > 8192) FAIL(NMSLIB_ERROR_QUERY_TOO_LARGE, "nshards * k must not exceed 8192");
     return guarded(NMSLIB_ERROR_RUNTIME, "merge_topk", [&] {
         if (query_count)
-            gfxknn::hip_check(gfxknn::launch_merge_topk(d_dists_in, d_ids_in, (int)nshards, (int)query_count, (int)k,
-                                                        d_dists_out, d_ids_out, static_cast<hipStream_t>(stream)),
+            gfxknn::hip_check(gfxknn::launch_merge_topk(d_dists_in, d_ids_in, shard_stride, (int)nshards, (int)query_count,
+                                                        (int)k, d_dists_out, d_ids_out, static_cast<hipStream_t>(stream)),
                               "merge_topk");
     });
+}
+
+nmslib_error_t nmslib_gpu_merge_topk(const float* d_dists_in, const int32_t* d_ids_in, size_t nshards,
+                                     size_t query_count, size_t k, float* d_dists_out, int32_t* d_ids_out,
+                                     void* stream) {
+    return nmslib_gpu_merge_topk_strided(d_dists_in, d_ids_in, query_count * k, nshards, query_count, k, d_dists_out,
+                                         d_ids_out, stream);
 }
 
 nmslib_error_t nmslib_gpu_kernel_timing(nmslib_index_handle_t handle, int enable, double* total_ms,

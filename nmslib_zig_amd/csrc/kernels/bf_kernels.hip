@@ -1054,8 +1054,8 @@ __global__ void pair_distance_kernel(int space, const void* a, const void* b, in
 }
 
 // per-shard top-k lists -> global top-k by (distance, id); one wave per query
-__global__ void merge_topk_kernel(const float* dists_in, const int32_t* ids_in, int nshards, int nq,
-                                  int k, float* dists_out, int32_t* ids_out) {
+__global__ void merge_topk_kernel(const float* dists_in, const int32_t* ids_in, size_t shard_stride, int nshards,
+                                  int nq, int k, float* dists_out, int32_t* ids_out) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     u64* keys = reinterpret_cast<u64*>(smem);
     const int q = blockIdx.x, tid = threadIdx.x;
@@ -1065,7 +1065,7 @@ __global__ void merge_topk_kernel(const float* dists_in, const int32_t* ids_in, 
         u64 key = ~0ull;
         if (i < total) {
             const int s = i / k, j = i - s * k;
-            const size_t off = ((size_t)s * nq + q) * k + j;
+            const size_t off = (size_t)s * shard_stride + (size_t)q * k + j;
             const int32_t id = ids_in[off];
             if (id >= 0) key = ((u64)f32_ord(dists_in[off]) << 32) | (uint32_t)id;
         }
@@ -1331,15 +1331,15 @@ hipError_t launch_pair_distance(int space, const void* a, const void* b, int dim
     hipLaunchKernelGGL(pair_distance_kernel, dim3(1), dim3(64), 0, s, space, a, b, dim, out);
     return hipGetLastError();
 }
-hipError_t launch_merge_topk(const float* dists_in, const int32_t* ids_in, int nshards, int nq, int k,
-                             float* dists_out, int32_t* ids_out, hipStream_t s) {
+hipError_t launch_merge_topk(const float* dists_in, const int32_t* ids_in, size_t shard_stride, int nshards, int nq,
+                             int k, float* dists_out, int32_t* ids_out, hipStream_t s) {
     const int P = host_next_pow2(nshards * k < 2 ? 2 : nshards * k);
     const size_t lds = (size_t)P * 8;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(merge_topk_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(merge_topk_kernel, dim3(nq), dim3(256), lds, s, dists_in, ids_in, nshards, nq, k,
-                       dists_out, ids_out);
+    hipLaunchKernelGGL(merge_topk_kernel, dim3(nq), dim3(256), lds, s, dists_in, ids_in, shard_stride, nshards, nq,
+                       k, dists_out, ids_out);
     return hipGetLastError();
 }
 

@@ -151,7 +151,8 @@ hipError_t launch_range_search(int space, const void* rows, int ld, int n, const
                                int32_t* out_ids, float* out_dists, hipStream_t s);
 
 // ---- shard merge ---------------------------------------------------------------------------
-hipError_t launch_merge_topk(const float* dists_in, const int32_t* ids_in, int nshards, int nq,
+// shard s's lists start at dists_in + s*shard_stride / ids_in + s*shard_stride (elements)
+hipError_t launch_merge_topk(const float* dists_in, const int32_t* ids_in, size_t shard_stride, int nshards, int nq,
                              int k, float* dists_out, int32_t* ids_out, hipStream_t s);
 
 }  // namespace gfxknn

@@ -26,6 +26,16 @@ def all_gather_topk(dist, dists, ids):
     return g_d.view((world,) + tuple(dists.shape)), g_i.view((world,) + tuple(ids.shape))
 
 
+def all_gather_topk_packed(dist, pack):
+    """pack: int32 [2, Q, k] on this rank (ids, then the float32 distances' bit patterns) ->
+    int32 [world, 2, Q, k] on every rank with ONE collective (8 B * Q * k per rank)."""
+    import torch
+    world = dist.get_world_size()
+    g = torch.empty((world * pack.shape[0],) + tuple(pack.shape[1:]), dtype=pack.dtype, device=pack.device)
+    dist.all_gather_into_tensor(g, pack.contiguous())
+    return g.view((world,) + tuple(pack.shape))
+
+
 def merge_topk_reference(g_d, g_i, k):
     """Host statement of what nmslib_gpu_merge_topk computes (used by the CPU protocol test):
     per query the k smallest (distance, id) pairs over all shards; id < 0 entries are padding."""

@@ -205,3 +205,35 @@ def test_range_query_matches_oracle_scan(space):
     if space != "negdotprod":
         assert len(idx.rangeQueryFill(X[7], -1.0, 10)[0]) == 0
     idx.close()
+
+
+def test_shard_merge_kernels_match_host_statement():
+    """nmslib_gpu_merge_topk / _strided (the step after the RCCL all-gather) against shard.merge_topk_reference:
+    3 shards, padding entries (-1 / +inf), equal distances across shards ordered by id."""
+    import torch
+    from nmslib_zig_amd.shard import merge_topk_reference
+    rng = np.random.default_rng(7)
+    world, nq, k = 3, 37, 10
+    d = np.sort(rng.integers(0, 40, (world, nq, k)).astype(np.float32), axis=2)       # many ties
+    i = rng.permutation(world * nq * k).astype(np.int32).reshape(world, nq, k)
+    i[2, :, 7:] = -1
+    d[2, :, 7:] = np.inf
+    want_d, want_i = merge_topk_reference(d, i, k)
+    dev = torch.device("cuda:0")
+    gd, gi = torch.from_numpy(d).to(dev), torch.from_numpy(i).to(dev)
+    od = torch.empty((nq, k), dtype=torch.float32, device=dev)
+    oi = torch.empty((nq, k), dtype=torch.int32, device=dev)
+    s = torch.cuda.current_stream().cuda_stream
+    nz._check(nz.lib().nmslib_gpu_merge_topk(gd.data_ptr(), gi.data_ptr(), world, nq, k, od.data_ptr(), oi.data_ptr(), s))
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(oi.cpu().numpy(), want_i)
+    np.testing.assert_array_equal(od.cpu().numpy(), want_d)
+    # packed [world][2][nq][k] int32 layout of one all-gather
+    pack = torch.from_numpy(np.stack([i, d.view(np.int32)], axis=1).copy()).to(dev)
+    od.zero_()
+    oi.zero_()
+    nz._check(nz.lib().nmslib_gpu_merge_topk_strided(pack.data_ptr() + nq * k * 4, pack.data_ptr(), 2 * nq * k, world,
+                                                     nq, k, od.data_ptr(), oi.data_ptr(), s))
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(oi.cpu().numpy(), want_i)
+    np.testing.assert_array_equal(od.cpu().numpy(), want_d)

@@ -110,3 +110,21 @@ def test_gpu_build_tiny_and_delaunay0():
     ids, _, _ = idx.knnQueryBatch(Q, 10)
     assert refio.recall_nmslib(ids, ei, ed, 10) >= 0.9
     idx.close()
+
+
+@pytest.mark.parametrize("space", ["l1", "linf", "angulardist", "negdotprod"])
+def test_gpu_build_other_spaces_recall_on_par_with_host_build(space):
+    n, nq, k = 8000, 200, 10
+    X, Q = refio.s_lowrank(n, 48, 93), refio.s_lowrank(nq, 48, 94)
+    bf = make_index(space, "brute_force", X)
+    ei, ed, _ = bf.knnQueryBatch(Q, 2 * k)
+    bf.close()
+    rec = {}
+    for mode in (0, 1):
+        idx = make_index(space, "hnsw", X, M=12, efConstruction=80, gpu_build=mode,
+                         **({"indexThreadQty": 4} if mode == 0 else {}))
+        idx.setQueryTimeParams(efSearch=60)
+        ids, _, _ = idx.knnQueryBatch(Q, k)
+        rec[mode] = refio.recall_nmslib(ids, ei, ed, k)
+        idx.close()
+    assert rec[1] >= rec[0] - 0.02, rec

@@ -11,7 +11,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from nmslib_zig_amd.shard import all_gather_topk, merge_topk_reference, shard_range
+from nmslib_zig_amd.shard import all_gather_topk, all_gather_topk_packed, merge_topk_reference, shard_range
 from tests import orc, refio
 
 
@@ -31,6 +31,12 @@ def _worker(rank, world, port, space, n, k, q_out):
         m_d, m_i = merge_topk_reference(g_d.numpy(), g_i.numpy(), k)
         full_pos, full_d, _ = orc.seq_search(space, X, Q, k)
         ok = np.array_equal(m_i, full_pos) and np.array_equal(m_d, full_d)
+        # the packed form bench.py uses: ids and distance bit patterns in ONE all-gather
+        pack = torch.from_numpy(np.stack([gid, d.astype(np.float32).view(np.int32)]))
+        g = all_gather_topk_packed(dist, pack).numpy()
+        assert g.shape == (world, 2, Q.shape[0], k)
+        p_d, p_i = merge_topk_reference(g[:, 1].copy().view(np.float32), g[:, 0], k)
+        ok = ok and np.array_equal(p_i, full_pos) and np.array_equal(p_d, full_d)
         if rank == 0:
             q_out.put(bool(ok))
     finally:
