@@ -88,8 +88,10 @@ __device__ __forceinline__ void frontier_distances(const HnswDeviceGraph& g, con
         int ids[4];
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
+            // slots past m re-read the last row (a cache hit) instead of branching: a load under its own
+            // exec-masked branch is followed by a full vmcnt(0) wait, which serialises the whole gather
             const int idx = base_i + p * 8 + g8;
-            ids[p] = idx < m ? nbr[idx] : -1;
+            ids[p] = nbr[idx < m ? idx : m - 1];
         }
         if constexpr (DistTraits<SPACE>::kU8) {
             // 128-byte rows: one 16-byte load per lane; exact integer n1 + n2 - 2*dot
@@ -98,12 +100,10 @@ __device__ __forceinline__ void frontier_distances(const HnswDeviceGraph& g, con
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
                 int dsum = 0;
-                if (ids[p] >= 0) {
-                    const i32x4 bb = *reinterpret_cast<const i32x4*>(
-                        reinterpret_cast<const uint8_t*>(g.rows) + (size_t)ids[p] * 128 + sub * 16);
+                const i32x4 bb = *reinterpret_cast<const i32x4*>(
+                    reinterpret_cast<const uint8_t*>(g.rows) + (size_t)ids[p] * 128 + sub * 16);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) dsum = __builtin_amdgcn_udot4(qq[j], bb[j], dsum, false);
-                }
+                for (int j = 0; j < 4; ++j) dsum = __builtin_amdgcn_udot4(qq[j], bb[j], dsum, false);
                 dots[p] = dsum;
             }
 #pragma unroll
@@ -115,17 +115,35 @@ __device__ __forceinline__ void frontier_distances(const HnswDeviceGraph& g, con
         } else {
             float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
             const float* rows = reinterpret_cast<const float*>(g.rows);
-#pragma unroll 4
-            for (int d = sub * 4; d < g.ldv; d += 32) {
-                const f32x4 qq = *reinterpret_cast<const f32x4*>(qv + d);
-                f32x4 bb[4];
+            // 128 floats of the 4 rows per pass: all 16 row loads are issued before the first one is waited for
+            // (random 512-byte gathers are latency-bound: the loads in flight per wave are the throughput).
+            // Out-of-range tails read a clamped address and are zeroed on both sides, so no load sits under
+            // a divergent branch.
+            const float* rp[4];
 #pragma unroll
-                for (int p = 0; p < 4; ++p) {
-                    bb[p] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    if (ids[p] >= 0) bb[p] = *reinterpret_cast<const f32x4*>(rows + (size_t)ids[p] * g.ldv + d);
+            for (int p = 0; p < 4; ++p) rp[p] = rows + (size_t)ids[p] * g.ldv;
+            const int dlast = g.ldv - 4;
+            for (int d0 = sub * 4; d0 < g.ldv; d0 += 128) {
+                f32x4 bb[4][4];
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int d = d0 + 32 * it;
+                    const int dc = d < dlast ? d : dlast;
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) bb[it][p] = *reinterpret_cast<const f32x4*>(rp[p] + dc);
                 }
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int p = 0; p < 4; ++p) accum4<SPACE>(qq, bb[p], s0[p], s1[p], s2[p]);
+                for (int it = 0; it < 4; ++it) {
+                    const int d = d0 + 32 * it;
+                    const bool ok = d < g.ldv;
+                    const int dc = d < dlast ? d : dlast;
+                    f32x4 qq = *reinterpret_cast<const f32x4*>(qv + dc);
+                    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+                    qq = ok ? qq : zero;
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) accum4<SPACE>(qq, ok ? bb[it][p] : zero, s0[p], s1[p], s2[p]);
+                }
             }
 #pragma unroll
             for (int p = 0; p < 4; ++p) {

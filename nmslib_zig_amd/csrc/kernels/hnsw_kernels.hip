@@ -14,6 +14,9 @@
 // per lane per step, up to 32 rows in flight per wave - with the distance fused into the
 // gather and an 8-lane shuffle reduction.  The sorted array lives in LDS and is shifted by
 // all lanes at once.  ndc / hops counters feed the roofline.
+#include <cstdio>
+#include <cstdlib>
+
 #include "hnsw_common.cuh"
 #include "kernels.hpp"
 
@@ -39,7 +42,11 @@ struct HnswArgs {
     const int32_t* start_nodes;  // [nq] start node (>= 0) or -1 = descend from the entry point; or NULL
     int level;
     int table_size, table_shift;
+    int prof;  // NMSLIB_HNSW_PROF: accumulate per-phase cycles into g_hnsw_prof (experiments only)
 };
+
+// [0] descent, [1] pick + adjacency, [2] visited filter, [3] gather + distances, [4] accept + sort, [5] inserts, [6] waves
+__device__ unsigned long long g_hnsw_prof[8];
 
 constexpr uint32_t HT_EMPTY = 0xFFFFFFFFu;
 constexpr int SA_EMAX_MAX = 16;  // sorted array up to 64*16 = 1024 items
@@ -198,6 +205,16 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(HnswArgs a) {
     };
     int cursor = 0;
     int pre_node = -1, pre_v = 0;
+    long long pc[6] = {0, 0, 0, 0, 0, 0};
+    long long pt = a.prof ? (long long)__builtin_readcyclecounter() : 0;
+    auto lap = [&](int ph) __attribute__((always_inline)) {
+        if (a.prof) {
+            const long long now = (long long)__builtin_readcyclecounter();
+            pc[ph] += now - pt;
+            pt = now;
+        }
+    };
+    lap(0);
     while (true) {
         const int lim = n < a.ef ? n : a.ef;
         // first unused item at or after cur
@@ -235,6 +252,7 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(HnswArgs a) {
             }
         }
         const int cntn = __builtin_amdgcn_readfirstlane(v);
+        lap(1);
         const int nb = __shfl(v, lane + 1, 64);
         bool isn = false;
         if (lane < cntn) isn = visit((uint32_t)nb);
@@ -247,9 +265,11 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(HnswArgs a) {
             break;
         }
         __builtin_amdgcn_wave_barrier();
+        lap(2);
         if (m == 0) continue;
         ndc += m;
         frontier_distances<SPACE>(g, qv, qb, qnorm, nbr, nd, m, lane);
+        lap(3);
 
         // accept d < topKey || size < ef   (:240)
         float dj = INFINITY;
@@ -278,6 +298,7 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(HnswArgs a) {
         }
         __builtin_amdgcn_wave_barrier();
 
+        lap(4);
         // SortArrBI::push_or_replace_non_empty_exp for each, in order (sort_arr_bi.h:159-199)
         for (int t = 0; t < m2; ++t) {
             const float key = sk[t];
@@ -351,6 +372,11 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(HnswArgs a) {
             }
             __builtin_amdgcn_wave_barrier();
         }
+        lap(5);
+    }
+    if (a.prof && lane == 0) {
+        for (int i = 0; i < 6; ++i) atomicAdd(&g_hnsw_prof[i], (unsigned long long)pc[i]);
+        atomicAdd(&g_hnsw_prof[6], 1ull);
     }
 
     // ---- results: first k items, ties ordered by internal id (KNNQueue holds
@@ -464,6 +490,8 @@ hipError_t launch_hnsw_search_ex(const HnswDeviceGraph& g, const HnswSearchPlan&
     a.out_hops = out_hops;
     a.out_hops_up = out_hops_up;
     a.status = status;
+    static const int prof = getenv("NMSLIB_HNSW_PROF") ? atoi(getenv("NMSLIB_HNSW_PROF")) : 0;
+    a.prof = (prof && !query_rows) ? 1 : 0;
     a.nq = p.nq;
     a.k = p.k;
     a.ef = p.ef;
@@ -471,6 +499,20 @@ hipError_t launch_hnsw_search_ex(const HnswDeviceGraph& g, const HnswSearchPlan&
     a.capa = (p.cap + 3) & ~3;
     a.table_size = p.table_size;
     a.table_shift = p.table_size ? 32 - ilog2(p.table_size) : 0;
+    if (a.prof) {
+        hipError_t pe = hipErrorInvalidValue;
+        if (g.space == SP_L2SQR) pe = launch_space<SP_L2SQR>(a, p, s);
+        else if (g.space == SP_NORMCOS) pe = launch_space<SP_NORMCOS>(a, p, s);
+        unsigned long long h[8] = {0};
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_hnsw_prof), sizeof(h));
+        unsigned long long z[8] = {0};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_hnsw_prof), z, sizeof(z));
+        const double w = h[6] ? (double)h[6] : 1.0;
+        fprintf(stderr, "[hnsw_search] cycles/query: descent %.0f pick+adj %.0f visited %.0f gather %.0f accept %.0f insert %.0f\n",
+                h[0] / w, h[1] / w, h[2] / w, h[3] / w, h[4] / w, h[5] / w);
+        return pe;
+    }
     switch (g.space) {
         case SP_L2SQR: return launch_space<SP_L2SQR>(a, p, s);
         case SP_L2: return launch_space<SP_L2>(a, p, s);
