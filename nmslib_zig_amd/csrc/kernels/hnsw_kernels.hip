@@ -204,7 +204,7 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(HnswArgs a) {
         return (lane <= g.maxM) ? g.up_links[g.up_off[c] + (int64_t)(a.level - 1) * (g.maxM + 1) + lane] : 0;
     };
     int cursor = 0;
-    int pre_node = -1, pre_v = 0;
+    int pre_node = -1, pre_v = 0, pre2_node = -1, pre2_v = 0;
     long long pc[6] = {0, 0, 0, 0, 0, 0};
     long long pt = a.prof ? (long long)__builtin_readcyclecounter() : 0;
     auto lap = [&](int ph) __attribute__((always_inline)) {
@@ -235,22 +235,12 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(HnswArgs a) {
         // adjacency of c: [count][ids...]
         int v;
         if (c == pre_node) v = pre_v;
+        else if (c == pre2_node) v = pre2_v;
         else v = load_adj(c);
-        // guess the next expansion: the next unused item (true unless a closer one is inserted)
-        {
-            int fu2 = n;
-            for (int base = cursor; base < n && fu2 == n; base += 64) {
-                const int i = base + lane;
-                const u64 mk = __ballot(i < n && idu[i] >= 0);
-                if (mk) fu2 = base + (__ffsll((long long)mk) - 1);
-            }
-            if (fu2 < lim) {
-                pre_node = idu[fu2] & 0x7FFFFFFF;
-                pre_v = load_adj(pre_node);
-            } else {
-                pre_node = -1;
-            }
-        }
+        // Adjacency of the NEXT expansion, requested early so that its latency (a random HBM read under
+        // load: ~2 us) hides behind this expansion's gather and inserts.  Two guesses: (A) now, the next
+        // unused item of the array -- right unless this expansion finds something closer; (B) after the
+        // distances, the best newly accepted item when it is closer than (A).
         const int cntn = __builtin_amdgcn_readfirstlane(v);
         lap(1);
         const int nb = __shfl(v, lane + 1, 64);
@@ -266,6 +256,25 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(HnswArgs a) {
         }
         __builtin_amdgcn_wave_barrier();
         lap(2);
+        // (issued only now: v had to be waited for first, and vmcnt retires in order -- a younger
+        //  outstanding load in front of that wait would put its whole latency into it)
+        float pre_key = INFINITY;
+        {
+            int fu2 = n;
+            for (int base = cursor; base < n && fu2 == n; base += 64) {
+                const int i = base + lane;
+                const u64 mk = __ballot(i < n && idu[i] >= 0);
+                if (mk) fu2 = base + (__ffsll((long long)mk) - 1);
+            }
+            if (fu2 < lim) {
+                pre_node = idu[fu2] & 0x7FFFFFFF;
+                pre_key = keys[fu2];
+                pre_v = load_adj(pre_node);
+            } else {
+                pre_node = -1;
+            }
+            pre2_node = -1;
+        }
         if (m == 0) continue;
         ndc += m;
         frontier_distances<SPACE>(g, qv, qb, qnorm, nbr, nd, m, lane);
@@ -298,79 +307,147 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(HnswArgs a) {
         }
         __builtin_amdgcn_wave_barrier();
 
+        if (sk[0] <= pre_key) {  // guess (B)
+            pre2_node = si[0];
+            pre2_v = load_adj(pre2_node);
+        }
         lap(4);
-        // SortArrBI::push_or_replace_non_empty_exp for each, in order (sort_arr_bi.h:159-199)
+        // All accepted items at once when no two keys involved are equal (the normal case): the result of
+        // the reference's sequential push_or_replace_non_empty_exp calls is then the merge of the two sorted
+        // sequences cut at the capacity, so every old item moves up by the number of new keys below it and
+        // new item t lands at (#old keys below it) + t; the scan cursor rewinds to the first new position
+        // (hnsw_distfunc_opt.cc:261-266).  Equal keys (rare) take the exact sequential replay below.
+        bool tie = false;
+        float kreg[SA_EMAX];
+        int cntv[SA_EMAX];
+#pragma unroll
+        for (int e = 0; e < SA_EMAX; ++e) {
+            const int i = lane + 64 * e;
+            kreg[e] = (e * 64 < n && i < n) ? keys[i] : INFINITY;
+            cntv[e] = 0;
+        }
+        const float mykey = lane < m2 ? sk[lane] : INFINITY;
+        const int myid = lane < m2 ? si[lane] : -1;
+        int myless = 0;
         for (int t = 0; t < m2; ++t) {
-            const float key = sk[t];
-            const int id = si[t];
-            const float lastk = keys[n - 1];
-            if (lastk <= key) {
-                if (n < a.cap) {
-                    if (lane == 0) {
-                        keys[n] = key;
-                        idu[n] = id;
-                    }
-                    n++;
-                }
-            } else {
-                // insertion index.  Without a key equal to the new one in the array, the reference's
-                // exponential probe + lower_bound (sort_arr_bi.h:172-186) is simply the number of
-                // smaller keys: one parallel count.  With equal keys present (rare) the probe is
-                // replayed so the item lands inside the run exactly where the reference puts it.
-                int less = 0, leq = 0;
+            const float skt = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mykey), t));
+            int less = 0;
 #pragma unroll
-                for (int e = 0; e < SA_EMAX; ++e) {
-                    if (e * 64 < n) {
-                        const int i = lane + 64 * e;
-                        const float kv = i < n ? keys[i] : INFINITY;
-                        less += __popcll(__ballot(kv < key));
-                        leq += __popcll(__ballot(kv <= key));
-                    }
+            for (int e = 0; e < SA_EMAX; ++e) {
+                if (e * 64 < n) {
+                    less += __popcll(__ballot(kreg[e] < skt));
+                    cntv[e] += (skt < kreg[e]) ? 1 : 0;
+                    tie |= (skt == kreg[e]);
                 }
-                int p = less;
-                if (leq != less) {
-                    int curr = n - 1, prev = curr, dstep = 1;
-                    while (curr > 0 && keys[curr] > key) {
-                        prev = curr;
-                        curr -= dstep;
-                        dstep *= 2;
-                        if (dstep > curr) dstep = curr;
-                    }
-                    p = curr;
-                    for (int i = curr; i < prev && keys[i] < key; ++i) p = i + 1;
-                }
-                const int newn = n < a.cap ? n + 1 : a.cap;
-                float rk[SA_EMAX];
-                int ri[SA_EMAX];
+            }
+            if (lane == t) myless = less;
+        }
+        tie |= (lane + 1 < m2) && (mykey == __shfl_down(mykey, 1, 64));
+        if (!__any(tie)) {
+            int ireg[SA_EMAX];
 #pragma unroll
-                for (int e = 0; e < SA_EMAX; ++e) {
-                    if (e * 64 < newn) {
-                        const int i = lane + 64 * e;
-                        if (i > p && i < newn) {
-                            rk[e] = keys[i - 1];
-                            ri[e] = idu[i - 1];
+            for (int e = 0; e < SA_EMAX; ++e) {
+                const int i = lane + 64 * e;
+                ireg[e] = (e * 64 < n && i < n) ? idu[i] : 0;
+            }
+            const int newn = n + m2 < a.cap ? n + m2 : a.cap;
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int e = 0; e < SA_EMAX; ++e) {
+                const int i = lane + 64 * e;
+                if (e * 64 < n && i < n && cntv[e] > 0) {
+                    const int np = i + cntv[e];
+                    if (np < newn) {
+                        keys[np] = kreg[e];
+                        idu[np] = ireg[e];
+                    }
+                }
+            }
+            if (lane < m2) {
+                const int np = myless + lane;
+                if (np < newn) {
+                    keys[np] = mykey;
+                    idu[np] = myid;
+                }
+            }
+            const int first = __builtin_amdgcn_readlane(myless, 0);
+            if (first < cursor) cursor = first;
+            n = newn;
+            __builtin_amdgcn_wave_barrier();
+        } else {
+            // SortArrBI::push_or_replace_non_empty_exp for each, in order (sort_arr_bi.h:159-199)
+            for (int t = 0; t < m2; ++t) {
+                const float key = sk[t];
+                const int id = si[t];
+                const float lastk = keys[n - 1];
+                if (lastk <= key) {
+                    if (n < a.cap) {
+                        if (lane == 0) {
+                            keys[n] = key;
+                            idu[n] = id;
+                        }
+                        n++;
+                    }
+                } else {
+                    // insertion index.  Without a key equal to the new one in the array, the reference's
+                    // exponential probe + lower_bound (sort_arr_bi.h:172-186) is simply the number of
+                    // smaller keys: one parallel count.  With equal keys present (rare) the probe is
+                    // replayed so the item lands inside the run exactly where the reference puts it.
+                    int less = 0, leq = 0;
+    #pragma unroll
+                    for (int e = 0; e < SA_EMAX; ++e) {
+                        if (e * 64 < n) {
+                            const int i = lane + 64 * e;
+                            const float kv = i < n ? keys[i] : INFINITY;
+                            less += __popcll(__ballot(kv < key));
+                            leq += __popcll(__ballot(kv <= key));
                         }
                     }
+                    int p = less;
+                    if (leq != less) {
+                        int curr = n - 1, prev = curr, dstep = 1;
+                        while (curr > 0 && keys[curr] > key) {
+                            prev = curr;
+                            curr -= dstep;
+                            dstep *= 2;
+                            if (dstep > curr) dstep = curr;
+                        }
+                        p = curr;
+                        for (int i = curr; i < prev && keys[i] < key; ++i) p = i + 1;
+                    }
+                    const int newn = n < a.cap ? n + 1 : a.cap;
+                    float rk[SA_EMAX];
+                    int ri[SA_EMAX];
+    #pragma unroll
+                    for (int e = 0; e < SA_EMAX; ++e) {
+                        if (e * 64 < newn) {
+                            const int i = lane + 64 * e;
+                            if (i > p && i < newn) {
+                                rk[e] = keys[i - 1];
+                                ri[e] = idu[i - 1];
+                            }
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+    #pragma unroll
+                    for (int e = 0; e < SA_EMAX; ++e) {
+                        if (e * 64 < newn) {
+                            const int i = lane + 64 * e;
+                            if (i > p && i < newn) {
+                                keys[i] = rk[e];
+                                idu[i] = ri[e];
+                            }
+                        }
+                    }
+                    if (lane == 0) {
+                        keys[p] = key;
+                        idu[p] = id;
+                    }
+                    n = newn;
+                    if (p < cursor) cursor = p;  // :261-266
                 }
                 __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                for (int e = 0; e < SA_EMAX; ++e) {
-                    if (e * 64 < newn) {
-                        const int i = lane + 64 * e;
-                        if (i > p && i < newn) {
-                            keys[i] = rk[e];
-                            idu[i] = ri[e];
-                        }
-                    }
-                }
-                if (lane == 0) {
-                    keys[p] = key;
-                    idu[p] = id;
-                }
-                n = newn;
-                if (p < cursor) cursor = p;  // :261-266
             }
-            __builtin_amdgcn_wave_barrier();
         }
         lap(5);
     }
