@@ -42,8 +42,6 @@ def main():
     if "--workload" in args:
         workload = args[args.index("--workload") + 1]
     bench = ["python3", os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "3", "--no-cpu-baseline"] + args
-    if workload == "hnsw":
-        bench += ["--index-cache", "/tmp/bench_hnsw_index.bin"]   # build once, reuse across the counter passes
     out = os.path.join(ROOT, "gpurun_out", "prof")
     os.makedirs(out, exist_ok=True)
     env = dict(os.environ, TMPDIR="/tmp")
@@ -91,7 +89,8 @@ def main():
         agg = {}
         for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
             for row in csv.DictReader(open(f)):
-                k = row.get("Kernel_Name", "")
+                # key by (kernel, grid): bench.py's ground-truth call runs the same kernel on another batch shape
+                k = row.get("Kernel_Name", "") + " grid=" + str(row.get("Grid_Size", row.get("Grid_Size_X", "?")))
                 c = row.get("Counter_Name", "")
                 v = float(row.get("Counter_Value", 0) or 0)
                 e = agg.setdefault(k, {}).setdefault(c, [0.0, 0])
