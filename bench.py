@@ -311,6 +311,30 @@ def main():
         "recall_at_k": None if recall is None else round(float(recall), 4),
         "roofline": roof,
     }
+    if world == 1 and a.workload != "cos768":
+        # the reference's own host-pointer entry (nmslib_knn_query_batch): H2D of the batch + D2H of the results inside
+        # the call.  Reported beside the device-resident number, never as `value`.
+        import ctypes as C
+        h_ids = np.empty((nq, k), np.int32)
+        h_ds = np.empty((nq, k), np.float32)
+        res = (nz.Result * nq)()
+        for i in range(nq):
+            res[i] = nz.Result(h_ids[i].ctypes.data_as(C.POINTER(C.c_int32)), h_ds[i].ctypes.data_as(C.POINTER(C.c_float)), 0, k)
+        hsteps = max(3, min(a.steps, 10))
+        L = nz.lib()
+        if method == "hnsw":                      # (the HNSW index was closed for the ground-truth pass: rebuild it)
+            idx = nz.Index(space, method)
+            idx.addDenseBatch(X[lo:hi], np.arange(lo, hi, dtype=np.int32))
+            idx.buildIndex(M=16, efConstruction=200, **({"gpu_build": a.gpu_build} if a.gpu_build >= 0 else {}))
+            idx.setQueryTimeParams(efSearch=a.ef)
+        nz._check(L.nmslib_knn_query_batch(idx.h, Q.ctypes.data, nq, Q.shape[1], k, res, None, 0))
+        th = time.perf_counter()
+        for _ in range(hsteps):
+            nz._check(L.nmslib_knn_query_batch(idx.h, Q.ctypes.data, nq, Q.shape[1], k, res, None, 0))
+        th = (time.perf_counter() - th) / hsteps
+        out["host_entry"] = {"entry": "nmslib_knn_query_batch (host pointers, PCIe inside the call)",
+                             "ms_per_step": round(th * 1e3, 4), "queries_per_s": round(nq / th, 1),
+                             "matches_device_entry": bool(np.array_equal(h_ids, res_ids))}
     if world == 1 and not a.no_cpu_baseline:
         note("timing the CPU baseline (oracle/_ref) on a bounded sample")
         try:

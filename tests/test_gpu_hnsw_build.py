@@ -128,3 +128,24 @@ def test_gpu_build_other_spaces_recall_on_par_with_host_build(space):
         rec[mode] = refio.recall_nmslib(ids, ei, ed, k)
         idx.close()
     assert rec[1] >= rec[0] - 0.02, rec
+
+
+def test_gpu_build_edge_cases_duplicates_large_ef_large_m():
+    # duplicate rows (zero distances, ties everywhere), efConstruction above the LDS-table range, M near the cap
+    rng = np.random.default_rng(5)
+    base = rng.standard_normal((300, 16)).astype(np.float32)
+    X = np.concatenate([base, base[:200], base[:100]])                 # 600 rows, many exact duplicates
+    idx = make_index("l2", "hnsw", X, M=30, efConstruction=400, gpu_build=1)        # maxM0 = 60 (limit 62)
+    idx.setQueryTimeParams(efSearch=100)
+    ids, ds, cnt = idx.knnQueryBatch(base[:50], 3)
+    assert (cnt == 3).all() and np.allclose(ds[:, 0], 0.0)
+    for q in range(50):                                                # the three copies of row q come first
+        assert set(ids[q].tolist()) <= {q, q + 300, q + 500} if q < 100 else True
+    idx.close()
+    for n in (2, 3, 17):                                               # tiny graphs
+        idx = make_index("cosinesimil", "hnsw", base[:n], M=4, efConstruction=10, gpu_build=1)
+        ids, ds, cnt = idx.knnQueryBatch(base[:n], min(n, 2))
+        assert (ids[:, 0] == np.arange(n)).all()
+        idx.close()
+    with pytest.raises(nz.NmslibError):
+        make_index("l2", "hnsw", base, M=8, efConstruction=2000, gpu_build=1)
