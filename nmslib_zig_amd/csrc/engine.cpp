@@ -1029,7 +1029,7 @@ std::unique_ptr<Engine> Engine::load(const std::string& path, int data_type, int
             default: throw EngineError(Err::DataIO, "Unknown distance function code in index file");
         }
         if (data_type != 0) throw EngineError(Err::DataIO, "an optimized HNSW index holds dense float vectors");
-        if (off_l0 < off_data + 16 || mem_per_obj < off_l0 + (maxM0 + 1) * 4 || maxM0 > 62 || maxM > 62)
+        if (off_l0 < off_data + 16 || mem_per_obj < off_l0 + (maxM0 + 1) * 4 || maxM0 > 126 || maxM > 62)
             throw EngineError(Err::DataIO, "unsupported optimized index geometry");
         e.reset(new Engine(space, "hnsw", data_type, dist_type));
         const size_t dim = (off_l0 - off_data - 16) / 4;

@@ -406,8 +406,11 @@ class Builder {
 }  // namespace
 
 void hnsw_check_params(const HnswBuildParams& bp) {
-    if (bp.maxM0 > 62 || bp.maxM > 62 || bp.M < 1)
-        throw EngineError(Err::IndexBuildFailed, "HNSW: M/maxM/maxM0 must be in [1, 62] on the GPU engine");
+    // one wavefront walks a node: upper-level lists (maxM) and the selection (M) fit one word per lane,
+    // level-0 lists (maxM0) two words per lane
+    if (bp.M < 1 || bp.M > 62 || bp.maxM < 1 || bp.maxM > 62 || bp.maxM0 < 1 || bp.maxM0 > 126)
+        throw EngineError(Err::IndexBuildFailed,
+                          "HNSW: M and maxM must be in [1, 62] and maxM0 in [1, 126] on the GPU engine");
     if (bp.delaunay != 0 && bp.delaunay != 2)
         throw EngineError(Err::IndexBuildFailed, "HNSW: delaunay_type must be 0 or 2 on the GPU engine");
     if (bp.post != 0) throw EngineError(Err::IndexBuildFailed, "HNSW: post-processing (post=1,2) is not supported");

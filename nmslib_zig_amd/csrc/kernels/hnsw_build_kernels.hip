@@ -142,15 +142,17 @@ __global__ __launch_bounds__(64) void hnsw_build_link_kernel(BuildArgs a) {
     const HnswDeviceGraph& g = a.g;
     const int lane = threadIdx.x;
     if ((int)blockIdx.x >= *a.nactive) return;
+    constexpr int W = 128;  // list width: maxM0 <= 126 friends + the new node
     const int qfloats = DistTraits<SPACE>::kU8 ? 32 : g.ldv;
     float* qv = reinterpret_cast<float*>(smem);                 // [ldv]
-    float* nd = qv + qfloats;                                   // [64]
-    int* kept_id = reinterpret_cast<int*>(nd + 64);             // [64]
-    float* kept_d = reinterpret_cast<float*>(kept_id + 64);     // [64]
-    int* fl = reinterpret_cast<int*>(kept_d + 64);              // [64] current friends
-    int* sc_id = fl + 64;                                       // [64] friends + new node, sorted
-    float* sc_d = reinterpret_cast<float*>(sc_id + 64);         // [64]
-    int* rp = reinterpret_cast<int*>(sc_d + 64);                // [64] requests, sorted by new node
+    float* nd = qv + qfloats;                                   // [W]
+    int* kept_id = reinterpret_cast<int*>(nd + W);              // [W]
+    float* kept_d = reinterpret_cast<float*>(kept_id + W);      // [W]
+    int* fl = reinterpret_cast<int*>(kept_d + W);               // [W] current friends
+    int* sc_id = fl + W;                                        // [W] friends + new node, sorted
+    float* sc_d = reinterpret_cast<float*>(sc_id + W);          // [W]
+    float* td = sc_d + W;                                       // [W] unsorted distances of the same
+    int* rp = reinterpret_cast<int*>(td + W);                   // [64] requests, sorted by new node
     float* rd = reinterpret_cast<float*>(rp + 64);              // [64]
 
     const int t = a.active[blockIdx.x];
@@ -173,7 +175,7 @@ __global__ __launch_bounds__(64) void hnsw_build_link_kernel(BuildArgs a) {
     int32_t* L = adj_list(a, t);
     const int maxsz = a.level > 0 ? g.maxM : g.maxM0;
     int cnt = L[0];
-    if (lane < cnt) fl[lane] = L[1 + lane];
+    for (int i = lane; i < cnt; i += 64) fl[i] = L[1 + i];
     __builtin_amdgcn_wave_barrier();
 
     for (int r = 0; r < nreq; ++r) {
@@ -189,30 +191,33 @@ __global__ __launch_bounds__(64) void hnsw_build_link_kernel(BuildArgs a) {
         int qnorm;
         stage_row<SPACE>(g, t, qv, qnorm, lane);
         frontier_distances<SPACE>(g, qv, reinterpret_cast<const uint8_t*>(qv), qnorm, fl, nd, cnt, lane);
-        int idj = -1;
-        float dj = INFINITY;
-        if (lane < cnt) {
-            idj = fl[lane];
-            dj = nd[lane];
-        } else if (lane == cnt) {
-            idj = p;
-            dj = dp;
-        }
         const int n1 = cnt + 1;
-        int rank = 0;
-        for (int i = 0; i < n1; ++i) {
-            const float di = __shfl(dj, i, 64);
-            rank += (di < dj || (di == dj && i < lane)) ? 1 : 0;
+        for (int i = lane; i < cnt; i += 64) td[i] = nd[i];
+        if (lane == 0) {
+            td[cnt] = dp;
+            fl[cnt] = p;   // (slot cnt <= 126 is free: the list is rebuilt below)
         }
         __builtin_amdgcn_wave_barrier();
+        // rank sort by (distance, list position), up to two items per lane
+        const float da = lane < n1 ? td[lane] : INFINITY, db = lane + 64 < n1 ? td[lane + 64] : INFINITY;
+        int ra = 0, rb = 0;
+        for (int j = 0; j < n1; ++j) {
+            const float dj = td[j];
+            ra += (dj < da || (dj == da && j < lane)) ? 1 : 0;
+            rb += (dj < db || (dj == db && j < lane + 64)) ? 1 : 0;
+        }
         if (lane < n1) {
-            sc_id[rank] = idj;
-            sc_d[rank] = dj;
+            sc_id[ra] = fl[lane];
+            sc_d[ra] = da;
+        }
+        if (lane + 64 < n1) {
+            sc_id[rb] = fl[lane + 64];
+            sc_d[rb] = db;
         }
         __builtin_amdgcn_wave_barrier();
         const int nk = heuristic2<SPACE>(g, sc_id, sc_d, n1, n1 - 1, a.delaunay, qv, nd, kept_id, kept_d, lane);
         // refilled farthest first (hnsw.h:295-300)
-        if (lane < nk) fl[lane] = kept_id[nk - 1 - lane];
+        for (int i = lane; i < nk; i += 64) fl[i] = kept_id[nk - 1 - i];
         cnt = nk;
         __builtin_amdgcn_wave_barrier();
     }
@@ -220,7 +225,7 @@ __global__ __launch_bounds__(64) void hnsw_build_link_kernel(BuildArgs a) {
         L[0] = cnt;
         a.req_cnt[t] = 0;
     }
-    if (lane < maxsz) L[1 + lane] = lane < cnt ? fl[lane] : 0;
+    for (int i = lane; i < maxsz; i += 64) L[1 + i] = i < cnt ? fl[i] : 0;
 }
 
 // start node of each (node, level) search = closest result of the same node's search one level up
@@ -309,7 +314,7 @@ hipError_t launch_hnsw_build_link(const HnswBuildGraph& bg, int level, const int
     a.req_dist = const_cast<float*>(req_dist);
     a.req_cap = req_cap;
     const size_t qbytes = bg.g.space == SP_L2SQR_SIFT ? 128 : (size_t)bg.g.ldv * 4;
-    const size_t lds = qbytes + 9 * 64 * 4 + 16;
+    const size_t lds = qbytes + (7 * 128 + 2 * 64) * 4 + 16;
     BUILD_DISPATCH(hnsw_build_link_kernel, bg.g.space, a, max_active, lds, s)
 }
 

@@ -64,9 +64,10 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(HnswArgs a) {
     int* idu = reinterpret_cast<int*>(keys + a.capa);              // [capa]  id | used<<31
     const int qfloats = kU8 ? 32 : g.ldv;
     float* qv = reinterpret_cast<float*>(idu + a.capa);            // [ldv] (u8: 128 bytes)
-    int* nbr = reinterpret_cast<int*>(qv + qfloats);               // [64]
-    float* nd = reinterpret_cast<float*>(nbr + 64);                // [64]
-    float* sk = nd + 64;                                           // [64] accepted keys, sorted
+    const int nbcap = g.maxM0 > 62 ? 128 : 64;                     // neighbours of one expansion (maxM0 <= 126)
+    int* nbr = reinterpret_cast<int*>(qv + qfloats);               // [nbcap]
+    float* nd = reinterpret_cast<float*>(nbr + nbcap);             // [nbcap]
+    float* sk = nd + nbcap;                                        // [64] accepted keys, sorted
     int* si = reinterpret_cast<int*>(sk + 64);                     // [64] accepted ids
     uint32_t* table = reinterpret_cast<uint32_t*>(si + 64);        // [table_size]
     uint32_t* bits = BITSET ? a.bitset + (size_t)q * a.bitset_words : nullptr;
@@ -243,12 +244,22 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(HnswArgs a) {
         // distances, the best newly accepted item when it is closer than (A).
         const int cntn = __builtin_amdgcn_readfirstlane(v);
         lap(1);
-        const int nb = __shfl(v, lane + 1, 64);
+        const int nb = __shfl(v, lane + 1, 64);   // neighbours 0..62 (list words 1..63)
         bool isn = false;
-        if (lane < cntn) isn = visit((uint32_t)nb);
+        if (lane < cntn && lane < 63) isn = visit((uint32_t)nb);
         const u64 nmask = __ballot(isn);
-        const int m = __popcll(nmask);
+        int m = __popcll(nmask);
         if (isn) nbr[__popcll(nmask & ((1ull << lane) - 1ull))] = nb;
+        if (cntn > 63) {
+            // wide level-0 lists (maxM0 > 62, i.e. M >= 32): neighbours 63.. are list words 64.., read on demand
+            int nb2 = 0;
+            if (64 + lane <= g.maxM0) nb2 = g.links0[(size_t)c * (g.maxM0 + 1) + 64 + lane];
+            bool isn2 = false;
+            if (63 + lane < cntn) isn2 = visit((uint32_t)nb2);
+            const u64 nmask2 = __ballot(isn2);
+            if (isn2) nbr[m + __popcll(nmask2 & ((1ull << lane) - 1ull))] = nb2;
+            m += __popcll(nmask2);
+        }
         nvisited += m;
         if (!BITSET && nvisited > (a.table_size - (a.table_size >> 3))) {
             overflow = true;  // visited table nearly full: give up, the host re-runs with a bitset
@@ -280,173 +291,177 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(HnswArgs a) {
         frontier_distances<SPACE>(g, qv, qb, qnorm, nbr, nd, m, lane);
         lap(3);
 
-        // accept d < topKey || size < ef   (:240)
-        float dj = INFINITY;
-        int idj = -1;
-        bool acc = false;
-        if (lane < m) {
-            dj = nd[lane];
-            idj = nbr[lane];
-            acc = (dj < topKey) || (size0 < a.ef);
-        }
-        const u64 amask = __ballot(acc);
-        const int m2 = __popcll(amask);
-        if (m2 == 0) continue;
-        // ascending order of the accepted items (std::sort, :251); ties keep list order
-        int rank = 0;
-        for (u64 mm = amask; mm;) {
-            const int j = __ffsll((long long)mm) - 1;
-            mm &= mm - 1;
-            const float dother = __shfl(dj, j, 64);
-            rank += (dother < dj || (dother == dj && j < lane)) ? 1 : 0;
-        }
-        __builtin_amdgcn_wave_barrier();
-        if (acc) {
-            sk[rank] = dj;
-            si[rank] = idj;
-        }
-        __builtin_amdgcn_wave_barrier();
+        // (more than 64 new rows only with wide lists: rounds of 64; without equal keys the final array does
+        //  not depend on the order in which accepted items are merged in)
+        for (int r0 = 0; r0 < m; r0 += 64) {
+            // accept d < topKey || size < ef   (:240)
+            float dj = INFINITY;
+            int idj = -1;
+            bool acc = false;
+            if (r0 + lane < m) {
+                dj = nd[r0 + lane];
+                idj = nbr[r0 + lane];
+                acc = (dj < topKey) || (size0 < a.ef);
+            }
+            const u64 amask = __ballot(acc);
+            const int m2 = __popcll(amask);
+            if (m2 == 0) continue;
+            // ascending order of the accepted items (std::sort, :251); ties keep list order
+            int rank = 0;
+            for (u64 mm = amask; mm;) {
+                const int j = __ffsll((long long)mm) - 1;
+                mm &= mm - 1;
+                const float dother = __shfl(dj, j, 64);
+                rank += (dother < dj || (dother == dj && j < lane)) ? 1 : 0;
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (acc) {
+                sk[rank] = dj;
+                si[rank] = idj;
+            }
+            __builtin_amdgcn_wave_barrier();
 
-        if (sk[0] <= pre_key) {  // guess (B)
-            pre2_node = si[0];
-            pre2_v = load_adj(pre2_node);
-        }
-        lap(4);
-        // All accepted items at once when no two keys involved are equal (the normal case): the result of
-        // the reference's sequential push_or_replace_non_empty_exp calls is then the merge of the two sorted
-        // sequences cut at the capacity, so every old item moves up by the number of new keys below it and
-        // new item t lands at (#old keys below it) + t; the scan cursor rewinds to the first new position
-        // (hnsw_distfunc_opt.cc:261-266).  Equal keys (rare) take the exact sequential replay below.
-        bool tie = false;
-        float kreg[SA_EMAX];
-        int cntv[SA_EMAX];
-#pragma unroll
-        for (int e = 0; e < SA_EMAX; ++e) {
-            const int i = lane + 64 * e;
-            kreg[e] = (e * 64 < n && i < n) ? keys[i] : INFINITY;
-            cntv[e] = 0;
-        }
-        const float mykey = lane < m2 ? sk[lane] : INFINITY;
-        const int myid = lane < m2 ? si[lane] : -1;
-        int myless = 0;
-        for (int t = 0; t < m2; ++t) {
-            const float skt = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mykey), t));
-            int less = 0;
-#pragma unroll
-            for (int e = 0; e < SA_EMAX; ++e) {
-                if (e * 64 < n) {
-                    less += __popcll(__ballot(kreg[e] < skt));
-                    cntv[e] += (skt < kreg[e]) ? 1 : 0;
-                    tie |= (skt == kreg[e]);
-                }
+            if (sk[0] <= pre_key) {  // guess (B)
+                pre2_node = si[0];
+                pre2_v = load_adj(pre2_node);
             }
-            if (lane == t) myless = less;
-        }
-        tie |= (lane + 1 < m2) && (mykey == __shfl_down(mykey, 1, 64));
-        if (!__any(tie)) {
-            int ireg[SA_EMAX];
-#pragma unroll
+            lap(4);
+            // All accepted items at once when no two keys involved are equal (the normal case): the result of
+            // the reference's sequential push_or_replace_non_empty_exp calls is then the merge of the two sorted
+            // sequences cut at the capacity, so every old item moves up by the number of new keys below it and
+            // new item t lands at (#old keys below it) + t; the scan cursor rewinds to the first new position
+            // (hnsw_distfunc_opt.cc:261-266).  Equal keys (rare) take the exact sequential replay below.
+            bool tie = false;
+            float kreg[SA_EMAX];
+            int cntv[SA_EMAX];
+    #pragma unroll
             for (int e = 0; e < SA_EMAX; ++e) {
                 const int i = lane + 64 * e;
-                ireg[e] = (e * 64 < n && i < n) ? idu[i] : 0;
+                kreg[e] = (e * 64 < n && i < n) ? keys[i] : INFINITY;
+                cntv[e] = 0;
             }
-            const int newn = n + m2 < a.cap ? n + m2 : a.cap;
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int e = 0; e < SA_EMAX; ++e) {
-                const int i = lane + 64 * e;
-                if (e * 64 < n && i < n && cntv[e] > 0) {
-                    const int np = i + cntv[e];
-                    if (np < newn) {
-                        keys[np] = kreg[e];
-                        idu[np] = ireg[e];
-                    }
-                }
-            }
-            if (lane < m2) {
-                const int np = myless + lane;
-                if (np < newn) {
-                    keys[np] = mykey;
-                    idu[np] = myid;
-                }
-            }
-            const int first = __builtin_amdgcn_readlane(myless, 0);
-            if (first < cursor) cursor = first;
-            n = newn;
-            __builtin_amdgcn_wave_barrier();
-        } else {
-            // SortArrBI::push_or_replace_non_empty_exp for each, in order (sort_arr_bi.h:159-199)
+            const float mykey = lane < m2 ? sk[lane] : INFINITY;
+            const int myid = lane < m2 ? si[lane] : -1;
+            int myless = 0;
             for (int t = 0; t < m2; ++t) {
-                const float key = sk[t];
-                const int id = si[t];
-                const float lastk = keys[n - 1];
-                if (lastk <= key) {
-                    if (n < a.cap) {
-                        if (lane == 0) {
-                            keys[n] = key;
-                            idu[n] = id;
-                        }
-                        n++;
-                    }
-                } else {
-                    // insertion index.  Without a key equal to the new one in the array, the reference's
-                    // exponential probe + lower_bound (sort_arr_bi.h:172-186) is simply the number of
-                    // smaller keys: one parallel count.  With equal keys present (rare) the probe is
-                    // replayed so the item lands inside the run exactly where the reference puts it.
-                    int less = 0, leq = 0;
+                const float skt = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mykey), t));
+                int less = 0;
     #pragma unroll
-                    for (int e = 0; e < SA_EMAX; ++e) {
-                        if (e * 64 < n) {
-                            const int i = lane + 64 * e;
-                            const float kv = i < n ? keys[i] : INFINITY;
-                            less += __popcll(__ballot(kv < key));
-                            leq += __popcll(__ballot(kv <= key));
-                        }
+                for (int e = 0; e < SA_EMAX; ++e) {
+                    if (e * 64 < n) {
+                        less += __popcll(__ballot(kreg[e] < skt));
+                        cntv[e] += (skt < kreg[e]) ? 1 : 0;
+                        tie |= (skt == kreg[e]);
                     }
-                    int p = less;
-                    if (leq != less) {
-                        int curr = n - 1, prev = curr, dstep = 1;
-                        while (curr > 0 && keys[curr] > key) {
-                            prev = curr;
-                            curr -= dstep;
-                            dstep *= 2;
-                            if (dstep > curr) dstep = curr;
-                        }
-                        p = curr;
-                        for (int i = curr; i < prev && keys[i] < key; ++i) p = i + 1;
-                    }
-                    const int newn = n < a.cap ? n + 1 : a.cap;
-                    float rk[SA_EMAX];
-                    int ri[SA_EMAX];
+                }
+                if (lane == t) myless = less;
+            }
+            tie |= (lane + 1 < m2) && (mykey == __shfl_down(mykey, 1, 64));
+            if (!__any(tie)) {
+                int ireg[SA_EMAX];
     #pragma unroll
-                    for (int e = 0; e < SA_EMAX; ++e) {
-                        if (e * 64 < newn) {
-                            const int i = lane + 64 * e;
-                            if (i > p && i < newn) {
-                                rk[e] = keys[i - 1];
-                                ri[e] = idu[i - 1];
+                for (int e = 0; e < SA_EMAX; ++e) {
+                    const int i = lane + 64 * e;
+                    ireg[e] = (e * 64 < n && i < n) ? idu[i] : 0;
+                }
+                const int newn = n + m2 < a.cap ? n + m2 : a.cap;
+                __builtin_amdgcn_wave_barrier();
+    #pragma unroll
+                for (int e = 0; e < SA_EMAX; ++e) {
+                    const int i = lane + 64 * e;
+                    if (e * 64 < n && i < n && cntv[e] > 0) {
+                        const int np = i + cntv[e];
+                        if (np < newn) {
+                            keys[np] = kreg[e];
+                            idu[np] = ireg[e];
+                        }
+                    }
+                }
+                if (lane < m2) {
+                    const int np = myless + lane;
+                    if (np < newn) {
+                        keys[np] = mykey;
+                        idu[np] = myid;
+                    }
+                }
+                const int first = __builtin_amdgcn_readlane(myless, 0);
+                if (first < cursor) cursor = first;
+                n = newn;
+                __builtin_amdgcn_wave_barrier();
+            } else {
+                // SortArrBI::push_or_replace_non_empty_exp for each, in order (sort_arr_bi.h:159-199)
+                for (int t = 0; t < m2; ++t) {
+                    const float key = sk[t];
+                    const int id = si[t];
+                    const float lastk = keys[n - 1];
+                    if (lastk <= key) {
+                        if (n < a.cap) {
+                            if (lane == 0) {
+                                keys[n] = key;
+                                idu[n] = id;
+                            }
+                            n++;
+                        }
+                    } else {
+                        // insertion index.  Without a key equal to the new one in the array, the reference's
+                        // exponential probe + lower_bound (sort_arr_bi.h:172-186) is simply the number of
+                        // smaller keys: one parallel count.  With equal keys present (rare) the probe is
+                        // replayed so the item lands inside the run exactly where the reference puts it.
+                        int less = 0, leq = 0;
+        #pragma unroll
+                        for (int e = 0; e < SA_EMAX; ++e) {
+                            if (e * 64 < n) {
+                                const int i = lane + 64 * e;
+                                const float kv = i < n ? keys[i] : INFINITY;
+                                less += __popcll(__ballot(kv < key));
+                                leq += __popcll(__ballot(kv <= key));
                             }
                         }
+                        int p = less;
+                        if (leq != less) {
+                            int curr = n - 1, prev = curr, dstep = 1;
+                            while (curr > 0 && keys[curr] > key) {
+                                prev = curr;
+                                curr -= dstep;
+                                dstep *= 2;
+                                if (dstep > curr) dstep = curr;
+                            }
+                            p = curr;
+                            for (int i = curr; i < prev && keys[i] < key; ++i) p = i + 1;
+                        }
+                        const int newn = n < a.cap ? n + 1 : a.cap;
+                        float rk[SA_EMAX];
+                        int ri[SA_EMAX];
+        #pragma unroll
+                        for (int e = 0; e < SA_EMAX; ++e) {
+                            if (e * 64 < newn) {
+                                const int i = lane + 64 * e;
+                                if (i > p && i < newn) {
+                                    rk[e] = keys[i - 1];
+                                    ri[e] = idu[i - 1];
+                                }
+                            }
+                        }
+                        __builtin_amdgcn_wave_barrier();
+        #pragma unroll
+                        for (int e = 0; e < SA_EMAX; ++e) {
+                            if (e * 64 < newn) {
+                                const int i = lane + 64 * e;
+                                if (i > p && i < newn) {
+                                    keys[i] = rk[e];
+                                    idu[i] = ri[e];
+                                }
+                            }
+                        }
+                        if (lane == 0) {
+                            keys[p] = key;
+                            idu[p] = id;
+                        }
+                        n = newn;
+                        if (p < cursor) cursor = p;  // :261-266
                     }
                     __builtin_amdgcn_wave_barrier();
-    #pragma unroll
-                    for (int e = 0; e < SA_EMAX; ++e) {
-                        if (e * 64 < newn) {
-                            const int i = lane + 64 * e;
-                            if (i > p && i < newn) {
-                                keys[i] = rk[e];
-                                idu[i] = ri[e];
-                            }
-                        }
-                    }
-                    if (lane == 0) {
-                        keys[p] = key;
-                        idu[p] = id;
-                    }
-                    n = newn;
-                    if (p < cursor) cursor = p;  // :261-266
                 }
-                __builtin_amdgcn_wave_barrier();
             }
         }
         lap(5);
@@ -498,7 +513,7 @@ HnswSearchPlan hnsw_make_plan(const HnswDeviceGraph& g, int nq, int k, int ef, b
     p.ef = ef;
     p.cap = ef > k ? ef : k;
     const bool u8 = g.space == SP_L2SQR_SIFT;
-    const size_t fixed = (size_t)((p.cap + 3) & ~3) * 8 + (u8 ? 128 : (size_t)g.ldv * 4) + 4 * 64 * 4;
+    const size_t fixed = (size_t)((p.cap + 3) & ~3) * 8 + (u8 ? 128 : (size_t)g.ldv * 4) + (size_t)(2 * (g.maxM0 > 62 ? 128 : 64) + 2 * 64) * 4;
     // expected visited nodes ~ (maxM0 * expansions); expansions ~ ef.  Size the table for 2x that
     // and never let LDS push residency below 4 waves per CU (160 KB / 4).
     int want = 1 << ilog2((g.maxM0 > 0 ? g.maxM0 : 32) * p.cap * 2);
@@ -551,7 +566,7 @@ hipError_t launch_hnsw_search_ex(const HnswDeviceGraph& g, const HnswSearchPlan&
                               int32_t* out_ndc, int32_t* out_hops, int32_t* out_hops_up,
                               int32_t* status, hipStream_t s) {
     if (p.nq == 0) return hipSuccess;
-    if (p.cap > 64 * SA_EMAX_MAX || g.maxM0 > 62 || g.maxM > 62) return hipErrorInvalidValue;
+    if (p.cap > 64 * SA_EMAX_MAX || g.maxM0 > 126 || g.maxM > 62) return hipErrorInvalidValue;
     HnswArgs a{};
     a.g = g;
     a.queries = queries;

@@ -127,3 +127,38 @@ def test_multithreaded_build_recall_200k():
     assert rec >= 0.97, rec                      # the reference reaches 0.976 at 200k / ef=200
     assert np.all(np.diff(ds, axis=1) >= 0)
     idx.close()
+
+
+def test_wide_level0_lists_m32_and_m48_same_graph_parity():
+    """M >= 32 (maxM0 = 2M > 62): level-0 lists span two words per lane.  Same graph as the reference
+    (indexThreadQty=1 host build) -> ids, distances and counters equal the oracle's; the GPU builder
+    reaches the same recall."""
+    n, D, nq, k = 12000, 32, 128, 10
+    X, Q = refio.s_gauss(n, D, 71), refio.s_gauss(nq, D, 72)     # iid data: lists fill up to maxM0
+    for M in (32, 48):
+        idx = make_index("l2", "hnsw", X, M=M, efConstruction=120, indexThreadQty=1)
+        g = orc.HnswGraph.build("l2", X, M, 120)
+        assert (g.links0()[:, 0] > 63).any()                        # the wide part is really exercised
+        for ef in (40, 150):
+            idx.setQueryTimeParams(efSearch=ef)
+            ids, ds, cnt = idx.knnQueryBatch(Q, k)
+            opos, odist, ocnt, ondc, ohops = g.search(Q, k, ef)
+            assert (ids == opos).mean() >= 0.999 and close_rel(ds, odist)
+            ndc, hops, _ = (x.astype(np.int64) for x in idx.read_counters(nq))
+            assert abs(ndc.mean() / ondc.mean() - 1) < 0.01 and np.mean(hops == ohops) >= 0.97
+        rec_host = (ids == opos).mean()
+        idx.close()
+        bf = make_index("l2", "brute_force", X)
+        ei, ed, _ = bf.knnQueryBatch(Q, 2 * k)
+        bf.close()
+        rec = {}
+        for mode in (0, 1):
+            idx = make_index("l2", "hnsw", X, M=M, efConstruction=120, gpu_build=mode,
+                             **({"indexThreadQty": 1} if mode == 0 else {}))
+            idx.setQueryTimeParams(efSearch=60)
+            ids, _, _ = idx.knnQueryBatch(Q, k)
+            rec[mode] = refio.recall_nmslib(ids, ei, ed ** 2, k)
+            idx.close()
+        assert rec[1] >= rec[0] - 0.02, (M, rec)
+    with pytest.raises(nz.NmslibError):
+        make_index("l2", "hnsw", X[:100], M=64)                     # maxM0 = 128 > 126
