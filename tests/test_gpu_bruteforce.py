@@ -237,3 +237,30 @@ def test_shard_merge_kernels_match_host_statement():
     torch.cuda.synchronize()
     np.testing.assert_array_equal(oi.cpu().numpy(), want_i)
     np.testing.assert_array_equal(od.cpu().numpy(), want_d)
+
+
+def test_full_size_properties_u8_1M_k100():
+    """BASELINE config 4 size (1M x 128 uint8, Q=4096, k=100): exact integer path at full size."""
+    n, nq, k = 1_000_000, 4096, 100
+    X = refio.s_sift_like(n, 44)
+    Q = X[::241][:nq].copy()                        # queries ARE base rows
+    idx = make_index("l2sqr_sift", "seq_search", X)
+    ids, ds, cnt = idx.knnQueryBatch(Q, k)
+    assert np.all(cnt == k) and np.all(ds[:, 0] == 0) and np.all(np.diff(ds, axis=1) >= 0)
+    assert all(len(set(r)) == k for r in ids[::64].tolist())
+    # rank 0 is the query's own row unless an identical row precedes it (ties order by position)
+    own = np.arange(nq) * 241
+    assert np.all(ids[:, 0] <= own)
+    # spot-check 8 queries against the oracle's full scan: distances identical, ids identical modulo ties
+    sel = np.arange(0, nq, 512)
+    opos, odist, _ = orc.seq_search("l2sqr_sift", X, Q[sel], k)
+    np.testing.assert_array_equal(ds[sel], odist)
+    from tests.gpuutil import ids_match_modulo_ties
+    assert ids_match_modulo_ties(ids[sel], ds[sel], opos, odist)
+    # checksum of checksums: the multiset of (distance) per query is invariant under a row permutation of the base
+    perm = np.random.default_rng(1).permutation(n)
+    idx2 = make_index("l2sqr_sift", "seq_search", X[perm])
+    _, ds_p, _ = idx2.knnQueryBatch(Q[:512], k)
+    np.testing.assert_array_equal(ds_p, ds[:512])
+    idx.close()
+    idx2.close()

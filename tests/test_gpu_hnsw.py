@@ -162,3 +162,30 @@ def test_wide_level0_lists_m32_and_m48_same_graph_parity():
         assert rec[1] >= rec[0] - 0.02, (M, rec)
     with pytest.raises(nz.NmslibError):
         make_index("l2", "hnsw", X[:100], M=64)                     # maxM0 = 128 > 126
+
+
+def test_full_size_c3_1M_gpu_build_recall_and_self_queries():
+    """BASELINE config 3 size (1M x 128, M=16, efConstruction=200, efSearch=128, k=10, Q=1024): the default
+    (GPU-batched) build, recall against exact GPU brute force, plus properties that need no CPU scan."""
+    n, D, nq, k = 1_000_000, 128, 1024, 10
+    X, Q = refio.s_lowrank(n, D, 42), refio.s_lowrank(nq, D, 43)
+    bf = make_index("l2", "seq_search", X)
+    gt_i, gt_d, _ = bf.knnQueryBatch(Q, 32)
+    bf.close()
+    idx = make_index("l2", "hnsw", X, M=16, efConstruction=200)
+    assert idx.stats()["build_seconds"] < 30                      # (the reference needs ~50 s on 16 threads)
+    idx.setQueryTimeParams(efSearch=128)
+    ids, ds, cnt = idx.knnQueryBatch(Q, k)
+    assert np.all(cnt == k) and np.all(np.diff(ds, axis=1) >= 0)
+    assert all(len(set(r)) == k for r in ids.tolist())
+    rec = refio.recall_nmslib(ids, gt_i, gt_d ** 2, k)
+    assert rec >= 0.99, rec                                       # reference graph: 0.9961 at the same efSearch
+    # every returned distance is the squared L2 of that pair (spot check through nmslib_get_distance = sqrt)
+    for q in (0, 500, 1023):
+        d = orc.space_distance("l2", Q[q], X[int(ids[q, 0])])
+        assert abs(d * d - ds[q, 0]) <= 1e-5 * max(1.0, ds[q, 0])
+    # stored rows as queries find themselves first
+    S = X[::3907][:256].copy()
+    ids2, ds2, _ = idx.knnQueryBatch(S, 1)
+    assert (ids2[:, 0] == np.arange(256) * 3907).mean() >= 0.995 and (ds2[:, 0] <= 1e-6).mean() >= 0.995
+    idx.close()
