@@ -56,6 +56,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--index-cache", default="", help="hnsw, 1 GPU: save the built index here / load it if present")
     ap.add_argument("--gpu-build", type=int, default=-1, help="hnsw: 1 = batched GPU construction, 0 = host, -1 = library default")
+    ap.add_argument("--index-extra", default="", help="hnsw: extra index parameters, k=v,k=v (experiments)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="queries in the CPU baseline sample (0 = auto)")
     return ap.parse_args()
 
@@ -174,7 +175,8 @@ def main():
         (idx.addUInt8Batch if u8 else idx.addDenseBatch)(X[lo:hi], ids)
         note("building index (rows -> HBM" + (", HNSW construction" if method == "hnsw" else "") + ")")
         if method == "hnsw":
-            idx.buildIndex(M=16, efConstruction=200, **({"gpu_build": a.gpu_build} if a.gpu_build >= 0 else {}))
+            extra = dict(kv.split("=") for kv in a.index_extra.split(",") if kv)
+            idx.buildIndex(M=16, efConstruction=200, **({"gpu_build": a.gpu_build} if a.gpu_build >= 0 else {}), **extra)
             note(f"graph built in {idx.stats()['build_seconds']:.2f}s")
             idx.setQueryTimeParams(efSearch=a.ef)
             if cache:
