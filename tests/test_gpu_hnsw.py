@@ -189,3 +189,21 @@ def test_full_size_c3_1M_gpu_build_recall_and_self_queries():
     ids2, ds2, _ = idx.knnQueryBatch(S, 1)
     assert (ids2[:, 0] == np.arange(256) * 3907).mean() >= 0.995 and (ds2[:, 0] <= 1e-6).mean() >= 0.995
     idx.close()
+
+
+def test_algotype_old_is_served_by_v1merge_with_equivalent_results():
+    """algoType=old (SearchOld, hnsw_distfunc_opt.cc:46-150: priority-queue best-first) is answered by the
+    V1Merge kernel.  Both explore with the same ef-bounded frontier rule, so on the same graph the result
+    sets coincide except for rare boundary cases; quantified here against the oracle's SearchOld."""
+    n, D, nq, k = 20000, 64, 256, 10
+    X, Q = refio.s_lowrank(n, D, 81), refio.s_lowrank(nq, D, 82)
+    idx = make_index("l2", "hnsw", X, M=16, efConstruction=100, indexThreadQty=1)
+    g = orc.HnswGraph.build("l2", X, 16, 100)
+    for ef in (20, 100):
+        idx.setQueryTimeParams(efSearch=ef, algoType="old")
+        ids, ds, _ = idx.knnQueryBatch(Q, k)
+        opos, odist, _, _, _ = g.search(Q, k, ef, algo="old")
+        agree = np.mean([len(set(a) & set(b)) / k for a, b in zip(ids.tolist(), opos.tolist())])
+        assert agree >= 0.995, (ef, agree)
+        assert close_rel(np.sort(ds, axis=1)[:, 0], np.sort(odist, axis=1)[:, 0])
+    idx.close()
