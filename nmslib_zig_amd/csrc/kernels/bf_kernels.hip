@@ -942,22 +942,43 @@ __global__ __launch_bounds__(256) void bf_rerank_kernel(RerankArgs a) {
     }
     __syncthreads();
     const int P = next_pow2(total < 2 ? 2 : total);
-    for (int j = wave; j < total; j += 4) {
-        const uint32_t pos = (uint32_t)keys[j];
-        u64 key;
-        if (a.space == SP_L2SQR_SIFT) {
-            const uint8_t* row = reinterpret_cast<const uint8_t*>(a.base) + (size_t)pos * 128;
-            const uint8_t* qq = reinterpret_cast<const uint8_t*>(a.queries) + (size_t)q * 128;
-            const int d = wave_exact_distance_u8(row, qq, lane);
-            key = ((u64)i32_ord(d) << 32) | pos;
-        } else {
-            const float* row = reinterpret_cast<const float*>(a.base) + (size_t)pos * a.ldb;
-            const float* qq = reinterpret_cast<const float*>(a.queries) + (size_t)q * a.ldb;
-            const float d = wave_exact_distance_f32(a.space, row, qq, a.dim, lane);
-            key = ((u64)f32_ord(d) << 32) | pos;
+    if (a.space != SP_L2SQR_SIFT && a.dim <= 256) {
+        // four survivors per wave and step, their rows requested together (see wave_exact_distance_f32_x4)
+        const float* qq = reinterpret_cast<const float*>(a.queries) + (size_t)q * a.ldb;
+        for (int j0 = wave * 4; j0 < total; j0 += 16) {
+            uint32_t pos[4];
+            const float* rows[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int j = j0 + r < total ? j0 + r : total - 1;
+                pos[r] = (uint32_t)keys[j];
+                rows[r] = reinterpret_cast<const float*>(a.base) + (size_t)pos[r] * a.ldb;
+            }
+            float d[4];
+            wave_exact_distance_f32_x4(a.space, rows, qq, a.dim, lane, d);
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (lane == 0 && j0 + r < total) keys[j0 + r] = ((u64)f32_ord(d[r]) << 32) | pos[r];
         }
-        __builtin_amdgcn_wave_barrier();
-        if (lane == 0) keys[j] = key;
+    } else {
+        for (int j = wave; j < total; j += 4) {
+            const uint32_t pos = (uint32_t)keys[j];
+            u64 key;
+            if (a.space == SP_L2SQR_SIFT) {
+                const uint8_t* row = reinterpret_cast<const uint8_t*>(a.base) + (size_t)pos * 128;
+                const uint8_t* qq = reinterpret_cast<const uint8_t*>(a.queries) + (size_t)q * 128;
+                const int d = wave_exact_distance_u8(row, qq, lane);
+                key = ((u64)i32_ord(d) << 32) | pos;
+            } else {
+                const float* row = reinterpret_cast<const float*>(a.base) + (size_t)pos * a.ldb;
+                const float* qq = reinterpret_cast<const float*>(a.queries) + (size_t)q * a.ldb;
+                const float d = wave_exact_distance_f32(a.space, row, qq, a.dim, lane);
+                key = ((u64)f32_ord(d) << 32) | pos;
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 0) keys[j] = key;
+        }
     }
     for (int i = total + tid; i < P; i += blockDim.x) keys[i] = ~0ull;
     __syncthreads();
@@ -1109,7 +1130,10 @@ BfPlan bf_make_plan(int n, int dim, int nq, int k, bool is_u8) {
     int by_sort = 4096 / p.kprime;
     int ns = want < by_rows ? want : by_rows;
     if (ns > by_sort) ns = by_sort;
-    if (ns > 64) ns = 64;
+    // one or two query tiles (single-query calls of nmslib_knn_query_fill): latency is the row stream of one
+    // workgroup, so cut the rows finer and put a workgroup on every CU
+    const int ns_cap = p.nqt <= 2 ? 256 : 64;
+    if (ns > ns_cap) ns = ns_cap;
     if (const char* e = getenv("NMSLIB_GPU_SPLITS")) ns = atoi(e);  // tuning experiments
     ns = (ns + 7) / 8 * 8;
     if (ns < 8) ns = 8;

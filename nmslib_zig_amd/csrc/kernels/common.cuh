@@ -156,6 +156,79 @@ __device__ __forceinline__ float wave_exact_distance_f32(int space, const float*
     }
 }
 
+// Four rows at once, dim <= 256: the same per-lane accumulation order and the same reductions as
+// wave_exact_distance_f32 (bit-identical results), but all row loads are issued before the first is used --
+// a re-rank over thousands of survivors is otherwise one exposed HBM latency per row.  Lanes past `dim`
+// read element 0 and contribute zeros on both sides.
+__device__ __forceinline__ void wave_exact_distance_f32_x4(int space, const float* const a[4],
+                                                           const float* __restrict__ q, int dim, int lane,
+                                                           float out[4]) {
+    float va[4][4], vq[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int d = lane + 64 * c;
+        const bool ok = d < dim;
+        const int di = ok ? d : 0;
+        const float qv = q[di];
+        vq[c] = ok ? qv : 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float x = a[r][di];
+            va[r][c] = ok ? x : 0.f;
+        }
+    }
+    const int nch = (dim + 63) >> 6;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+        if (space == SP_L2 || space == SP_L2SQR) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (c < nch) {
+                    const float t = va[r][c] - vq[c];
+                    s0 = fmaf(t, t, s0);
+                }
+            s0 = wave_sum(s0);
+            out[r] = space == SP_L2 ? sqrtf(s0) : s0;
+        } else if (space == SP_L1) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (c < nch) s0 += fabsf(va[r][c] - vq[c]);
+            out[r] = wave_sum(s0);
+        } else if (space == SP_LINF) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (c < nch) s0 = fmaxf(s0, fabsf(va[r][c] - vq[c]));
+            out[r] = wave_max(s0);
+        } else if (space == SP_NEGDOT || space == SP_NORMCOS) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (c < nch) s0 = fmaf(va[r][c], vq[c], s0);
+            s0 = wave_sum(s0);
+            if (space == SP_NEGDOT) {
+                out[r] = -s0;
+            } else {
+                const float cc = fmaxf(-1.0f, fminf(1.0f, s0));
+                out[r] = fmaxf(0.0f, 1.0f - cc);
+            }
+        } else {  // SP_COSINE, SP_ANGULAR
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (c < nch) {
+                    const float x = va[r][c], y = vq[c];
+                    s0 = fmaf(x, y, s0);
+                    s1 = fmaf(x, x, s1);
+                    s2 = fmaf(y, y, s2);
+                }
+            s0 = wave_sum(s0);
+            s1 = wave_sum(s1);
+            s2 = wave_sum(s2);
+            const float sim = normdot_finish(s0, s1, s2);
+            out[r] = space == SP_ANGULAR ? acosf(sim) : fmaxf(0.0f, 1.0f - sim);
+        }
+    }
+}
+
 // uint8 SIFT: exact integer squared L2 (distcomp_l2sqr_sift.cc:41-50 gives the same
 // integer as sum (a-b)^2).  128 bytes per row, 2 per lane.
 __device__ __forceinline__ int wave_exact_distance_u8(const uint8_t* __restrict__ a,
