@@ -681,8 +681,17 @@ void Engine::knn_device(const void* d_queries, size_t nq, size_t elem_count, siz
     if (d_n_ > 0 && elem_count != dim_)
         // SpaceLp::HiddenDistance CHECKs equal lengths (space_lp.cc:27-35) -> the query fails
         throw EngineError(Err::QueryExecutionFailed, "query dimension does not match the index");
-    if (method_ == Method::Brute) knn_brute(d_queries, nq, k, d_ids, d_dists, d_cnt, stream);
-    else knn_hnsw(d_queries, nq, k, d_ids, d_dists, d_cnt, stream);
+    // very large batches go through in slices: the per-query workspaces (candidate buffers, visited bitsets)
+    // stay bounded and every slice still fills the chip (the work counters then describe the last slice)
+    const size_t slice = method_ == Method::Brute ? 32768 : 65536;
+    const size_t qbytes = elem_count * elem_bytes();
+    for (size_t q0 = 0; q0 < nq; q0 += slice) {
+        const size_t m = std::min(slice, nq - q0);
+        const void* qs = static_cast<const char*>(d_queries) + q0 * qbytes;
+        int32_t* cnt = d_cnt ? d_cnt + q0 : nullptr;
+        if (method_ == Method::Brute) knn_brute(qs, m, k, d_ids + q0 * k, d_dists + q0 * k, cnt, stream);
+        else knn_hnsw(qs, m, k, d_ids + q0 * k, d_dists + q0 * k, cnt, stream);
+    }
 }
 
 void Engine::knn_brute(const void* d_queries, size_t nq, size_t k, int32_t* d_ids, float* d_dists, int32_t* d_cnt,

@@ -264,3 +264,19 @@ def test_full_size_properties_u8_1M_k100():
     np.testing.assert_array_equal(ds_p, ds[:512])
     idx.close()
     idx2.close()
+
+
+def test_batches_larger_than_one_slice_are_sliced_transparently():
+    """70 000 queries against a small base (brute-force slice = 32 768, HNSW 65 536): results equal the same
+    queries issued in small batches."""
+    X = refio.s_gauss(3000, 24, 95)
+    Q = refio.s_gauss(70_000, 24, 96)
+    for method, params in (("seq_search", {}), ("hnsw", dict(M=8, efConstruction=40, indexThreadQty=1))):
+        idx = make_index("l2", method, X, **params)
+        ids, ds, cnt = idx.knnQueryBatch(Q, 5)
+        for lo in (0, 32760, 65530):
+            i2, d2, c2 = idx.knnQueryBatch(Q[lo:lo + 50], 5)
+            np.testing.assert_array_equal(ids[lo:lo + 50], i2)
+            np.testing.assert_array_equal(ds[lo:lo + 50], d2)
+            np.testing.assert_array_equal(cnt[lo:lo + 50], c2)
+        idx.close()
