@@ -52,7 +52,9 @@ constexpr uint32_t HT_EMPTY = 0xFFFFFFFFu;
 constexpr int SA_EMAX_MAX = 16;  // sorted array up to 64*16 = 1024 items
 
 // EMAX = sorted-array items per lane (cap <= 64*EMAX): 2 for ef <= 128, 4 for <= 256, 16 otherwise.
-template <int SPACE, bool BITSET, int SA_EMAX>
+// WIDE: level-0 lists of more than 62 neighbours (maxM0 up to 126, i.e. M >= 32): second adjacency chunk,
+// 128-entry neighbour staging, two insertion rounds.  Kept out of the common instantiation.
+template <int SPACE, bool BITSET, int SA_EMAX, bool WIDE>
 __global__ __launch_bounds__(64) void hnsw_search_kernel(HnswArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const HnswDeviceGraph& g = a.g;
@@ -64,7 +66,7 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(HnswArgs a) {
     int* idu = reinterpret_cast<int*>(keys + a.capa);              // [capa]  id | used<<31
     const int qfloats = kU8 ? 32 : g.ldv;
     float* qv = reinterpret_cast<float*>(idu + a.capa);            // [ldv] (u8: 128 bytes)
-    const int nbcap = g.maxM0 > 62 ? 128 : 64;                     // neighbours of one expansion (maxM0 <= 126)
+    constexpr int nbcap = WIDE ? 128 : 64;                         // neighbours of one expansion (maxM0 <= 126)
     int* nbr = reinterpret_cast<int*>(qv + qfloats);               // [nbcap]
     float* nd = reinterpret_cast<float*>(nbr + nbcap);             // [nbcap]
     float* sk = nd + nbcap;                                        // [64] accepted keys, sorted
@@ -246,11 +248,11 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(HnswArgs a) {
         lap(1);
         const int nb = __shfl(v, lane + 1, 64);   // neighbours 0..62 (list words 1..63)
         bool isn = false;
-        if (lane < cntn && lane < 63) isn = visit((uint32_t)nb);
+        if (lane < cntn && (!WIDE || lane < 63)) isn = visit((uint32_t)nb);
         const u64 nmask = __ballot(isn);
         int m = __popcll(nmask);
         if (isn) nbr[__popcll(nmask & ((1ull << lane) - 1ull))] = nb;
-        if (cntn > 63) {
+        if (WIDE && cntn > 63) {
             // wide level-0 lists (maxM0 > 62, i.e. M >= 32): neighbours 63.. are list words 64.., read on demand
             int nb2 = 0;
             if (64 + lane <= g.maxM0) nb2 = g.links0[(size_t)c * (g.maxM0 + 1) + 64 + lane];
@@ -293,7 +295,7 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(HnswArgs a) {
 
         // (more than 64 new rows only with wide lists: rounds of 64; without equal keys the final array does
         //  not depend on the order in which accepted items are merged in)
-        for (int r0 = 0; r0 < m; r0 += 64) {
+        auto insert_round = [&](int r0) __attribute__((always_inline)) {
             // accept d < topKey || size < ef   (:240)
             float dj = INFINITY;
             int idj = -1;
@@ -305,7 +307,7 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(HnswArgs a) {
             }
             const u64 amask = __ballot(acc);
             const int m2 = __popcll(amask);
-            if (m2 == 0) continue;
+            if (m2 == 0) return;
             // ascending order of the accepted items (std::sort, :251); ties keep list order
             int rank = 0;
             for (u64 mm = amask; mm;) {
@@ -463,7 +465,9 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(HnswArgs a) {
                     __builtin_amdgcn_wave_barrier();
                 }
             }
-        }
+        };
+        insert_round(0);
+        if (WIDE && m > 64) insert_round(64);
         lap(5);
     }
     if (a.prof && lane == 0) {
@@ -534,23 +538,29 @@ HnswSearchPlan hnsw_make_plan(const HnswDeviceGraph& g, int nq, int k, int ef, b
     return p;
 }
 
-template <int SPACE, int EMAX>
-static hipError_t launch_space_e(const HnswArgs& a, const HnswSearchPlan& p, hipStream_t s) {
+template <int SPACE, int EMAX, bool WIDE>
+static hipError_t launch_space_w(const HnswArgs& a, const HnswSearchPlan& p, hipStream_t s) {
     hipError_t e;
     if (p.table_size == 0) {
-        auto kern = hnsw_search_kernel<SPACE, true, EMAX>;
+        auto kern = hnsw_search_kernel<SPACE, true, EMAX, WIDE>;
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(kern, dim3(a.nq), dim3(64), p.lds_bytes, s, a);
     } else {
-        auto kern = hnsw_search_kernel<SPACE, false, EMAX>;
+        auto kern = hnsw_search_kernel<SPACE, false, EMAX, WIDE>;
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(kern, dim3(a.nq), dim3(64), p.lds_bytes, s, a);
     }
     return hipGetLastError();
+}
+
+template <int SPACE, int EMAX>
+static hipError_t launch_space_e(const HnswArgs& a, const HnswSearchPlan& p, hipStream_t s) {
+    if (a.g.maxM0 > 62) return launch_space_w<SPACE, EMAX, true>(a, p, s);
+    return launch_space_w<SPACE, EMAX, false>(a, p, s);
 }
 
 template <int SPACE>
