@@ -295,7 +295,7 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(HnswArgs a) {
 
         // (more than 64 new rows only with wide lists: rounds of 64; without equal keys the final array does
         //  not depend on the order in which accepted items are merged in)
-        auto insert_round = [&](int r0) __attribute__((always_inline)) {
+        for (int r0 = 0; r0 < (WIDE ? m : 1); r0 += 64) {  // one trip unless the lists are wide
             // accept d < topKey || size < ef   (:240)
             float dj = INFINITY;
             int idj = -1;
@@ -307,7 +307,7 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(HnswArgs a) {
             }
             const u64 amask = __ballot(acc);
             const int m2 = __popcll(amask);
-            if (m2 == 0) return;
+            if (m2 == 0) continue;
             // ascending order of the accepted items (std::sort, :251); ties keep list order
             int rank = 0;
             for (u64 mm = amask; mm;) {
@@ -465,9 +465,7 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(HnswArgs a) {
                     __builtin_amdgcn_wave_barrier();
                 }
             }
-        };
-        insert_round(0);
-        if (WIDE && m > 64) insert_round(64);
+        }
         lap(5);
     }
     if (a.prof && lane == 0) {
