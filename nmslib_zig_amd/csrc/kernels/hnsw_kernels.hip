@@ -313,7 +313,8 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(HnswArgs a) {
             for (u64 mm = amask; mm;) {
                 const int j = __ffsll((long long)mm) - 1;
                 mm &= mm - 1;
-                const float dother = __shfl(dj, j, 64);
+                // (j comes from the ballot mask, so it is wave-uniform: v_readlane, not an LDS-routed shuffle)
+                const float dother = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dj), j));
                 rank += (dother < dj || (dother == dj && j < lane)) ? 1 : 0;
             }
             __builtin_amdgcn_wave_barrier();
