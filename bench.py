@@ -151,8 +151,14 @@ def main():
     torch.cuda.set_device(local % max(1, torch.cuda.device_count()))
     os.environ.setdefault("NMSLIB_GPU_DEVICE", str(torch.cuda.current_device()))
     dev = torch.device("cuda", torch.cuda.current_device())
+    # BENCH_BACKEND=gloo: rehearsal of the multi-rank protocol on ONE GPU (RCCL refuses two ranks on a device): the
+    # collective then goes through host memory; everything else (shards, packed layout, strided merge) is the real path
+    backend = os.environ.get("BENCH_BACKEND", "nccl")
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)   # RCCL over xGMI
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)   # RCCL over xGMI
+        else:
+            dist.init_process_group(backend)
 
     note(f"generating data: workload={a.workload} n={a.n}")
     X, Q = make_data(a)
@@ -200,7 +206,12 @@ def main():
         idx.knn_device(dq.data_ptr(), nq, Q.shape[1], k, d_ids.data_ptr(), d_ds.data_ptr(), d_cnt.data_ptr(),
                        stream.cuda_stream)
         if world > 1:
-            dist.all_gather_into_tensor(g_pack, pack)
+            if backend == "nccl":
+                dist.all_gather_into_tensor(g_pack, pack)
+            else:
+                g_host = torch.empty(g_pack.shape, dtype=g_pack.dtype)
+                dist.all_gather_into_tensor(g_host, pack.cpu())
+                g_pack.copy_(g_host)
             nz._check(nz.lib().nmslib_gpu_merge_topk_strided(g_pack.data_ptr() + nq * k * 4, g_pack.data_ptr(),
                                                              2 * nq * k, world, nq, k, m_ds.data_ptr(),
                                                              m_ids.data_ptr(), stream.cuda_stream))
@@ -237,6 +248,16 @@ def main():
     # ---- ground truth for recall (exact k-NN; tie-extended per NMSLIB's definition) ----------
     gt_ids = gt_d = None
     recall = None
+    if world > 1 and backend != "nccl" and method != "hnsw":
+        # rehearsal only: the merged result of the shards against one exact scan of the whole corpus
+        full = nz.Index(space, "seq_search", data_type="DenseUInt8Vector" if u8 else "DenseVector",
+                        dist_type="Int" if u8 else "Float")
+        (full.addUInt8Batch if u8 else full.addDenseBatch)(X)
+        full.buildIndex()
+        f_ids, f_ds, _ = full.knnQueryBatch(Q, k)
+        full.close()
+        recall = float((f_ids == res_ids).mean())
+        assert np.array_equal(f_ds, res_ds), "sharded + merged distances differ from the unsharded scan"
     if world == 1:
         if method == "hnsw":
             ngt = nq if a.workload == "hnsw" else min(nq, 256)
@@ -278,7 +299,7 @@ def main():
     tr = os.path.join(ROOT, "profiles", "traffic.json")       # PMC-measured HBM bytes/launch, if collected
     if os.path.exists(tr):
         try:
-            roof["traffic"] = json.load(open(tr)).get(a.workload) if a.n == 1_000_000 else None
+            roof["traffic"] = json.load(open(tr)).get(a.workload) if (a.n == 1_000_000 and world == 1) else None
         except Exception:
             pass
 
