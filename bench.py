@@ -299,7 +299,7 @@ def main():
     tr = os.path.join(ROOT, "profiles", "traffic.json")       # PMC-measured HBM bytes/launch, if collected
     if os.path.exists(tr):
         try:
-            roof["traffic"] = json.load(open(tr)).get(a.workload) if (a.n == 1_000_000 and world == 1) else None
+            roof["traffic"] = json.load(open(tr)).get(a.workload) if (a.n == 1_000_000 and world == 1 and a.dim in (128, 768) and not (a.workload == "bruteforce" and a.dim != 128)) else None
         except Exception:
             pass
 
