@@ -56,6 +56,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--index-cache", default="", help="hnsw, 1 GPU: save the built index here / load it if present")
     ap.add_argument("--gpu-build", type=int, default=-1, help="hnsw: 1 = batched GPU construction, 0 = host, -1 = library default")
+    ap.add_argument("--space", default="", help="bruteforce workload: another dense space (l1, linf, cosinesimil, ...)")
     ap.add_argument("--index-extra", default="", help="hnsw: extra index parameters, k=v,k=v (experiments)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="queries in the CPU baseline sample (0 = auto)")
     return ap.parse_args()
@@ -166,6 +167,8 @@ def main():
     lo, hi = rank * n // world, (rank + 1) * n // world          # this rank's row shard
     u8 = a.workload == "sift"
     space = "l2sqr_sift" if u8 else ("cosinesimil" if a.workload == "cos768" else "l2")
+    if a.space and a.workload == "bruteforce":
+        space = a.space
     method = "hnsw" if a.workload in ("hnsw", "cos768") else "seq_search"
     cache = a.index_cache if (method == "hnsw" and world == 1) else ""
     t_build = time.time()
