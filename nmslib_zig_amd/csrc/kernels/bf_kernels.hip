@@ -749,30 +749,13 @@ __global__ __launch_bounds__(256, 2) void bf_select_u8_kernel(BfArgsU8 a) {
     for (int i = 0; i < 8; ++i) t8[i] = INT32_MIN;
     int thr = kThr0;  // pass <=> score > thr
 
-    u64 pend0 = 0, pend1 = 0, pend2 = 0, pend3 = 0;
-    int npend = 0;
-    auto flush_pending = [&]() __attribute__((always_inline)) {
-        const int base = mycnt - npend;
-        if (npend > 0 && base < half) candq[base] = pend0;
-        if (npend > 1 && base + 1 < half) candq[base + 1] = pend1;
-        if (npend > 2 && base + 2 < half) candq[base + 2] = pend2;
-        if (npend > 3 && base + 3 < half) candq[base + 3] = pend3;
-        npend = 0;
-    };
+    // Appended keys are stored straight away: with LDS-DMA staging a store younger than the tile requests only
+    // makes the counted vmcnt wait at the end of the stage more conservative (DMA older than two stages has
+    // landed anyway), so the register-pending scheme of the f32 kernel buys nothing here.
     auto consider = [&](int s, int pos) __attribute__((always_inline)) {
         if (s > thr) {
             const u64 key = make_sel_key(i32_ord(s), (uint32_t)pos);
-            if (npend < 4) {
-                pend3 = pend2;
-                pend2 = pend1;
-                pend1 = pend0;
-                pend0 = key;
-                npend++;
-            } else {
-                flush_pending();
-                pend0 = key;
-                npend = 1;
-            }
+            if (mycnt < half) candq[mycnt] = key;
             mycnt++;
             if (track8 && s > t8[7]) {
                 int v = s;
@@ -787,7 +770,6 @@ __global__ __launch_bounds__(256, 2) void bf_select_u8_kernel(BfArgsU8 a) {
     };
     auto finish_stage = [&](bool lastst) __attribute__((always_inline)) {
         const bool need = lastst || (mycnt > half - BF_BN / 2);
-        if (__any(need)) flush_pending();
         if (lastst) {
             // final pass, every lane on its own half-buffer: drop what the final threshold rules out
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -886,7 +868,6 @@ __global__ __launch_bounds__(256, 2) void bf_select_u8_kernel(BfArgsU8 a) {
             acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(fb[ks], bq[ks], acc1, 0, 0, 0);
         }
         if (a.dbg & 1) asm volatile("" ::"v"(acc0[0]), "v"(acc1[0]), "v"(acc0[15]), "v"(acc1[15]));
-        flush_pending();
         if (a.xj > 0 && !(a.dbg & 256) && t > 0 && (((t - 1) & t) == 0 || ((t - 1) & 31) == 31)) exchange_counted();
         // tile t+1 must have landed; tiles t+2 .. t+5 (3 DMA instructions each) stay in flight.
         // Younger stores/loads of the epilogue only make this wait more conservative (in-order return).
