@@ -1,24 +1,34 @@
 #!/usr/bin/env python3
 """bench.py -- the reference's headline metric on MI355X.
 
-metric   : queries/sec @ recall@10, 1M x 128-D L2, batch=1024  (BASELINE.json)
-workload : default = BASELINE.json configs[1]: brute-force L2, 1M x 128 f32, k=10, batch 1024
-           (MFMA Q x B^T selection + exact re-rank).  --workload hnsw selects configs[2]
-           (HNSW M=16 efS=128), --workload sift configs[3] (uint8, k=100, batch 4096).
-step     : one batch of queries, already resident in HBM, through the device-resident entry of
-           the C ABI (nmslib_gpu_knn_query_batch_device) on torch's current stream.
-N > 1    : the corpus is sharded by rows over the ranks (one process per GPU); every rank
-           searches its shard for the same batch, per-shard top-k lists are all-gathered over
-           RCCL and merged on the GPU (nmslib_gpu_merge_topk).  Total corpus fixed -> "strong".
+metric   : queries/sec @ recall@10, 1M x 128-D L2, batch=1024; HBM GB/s vs peak  (BASELINE.json)
+workloads: the default run measures three of BASELINE.json's configs in one go:
+             C2 "bruteforce"  brute-force L2, 1M x 128 f32, k=10, batch 1024   -> the headline line
+             C3 "hnsw"        HNSW l2 1M x 128, M=16 efS=128, k=10, batch 1024 -> "workloads": {"hnsw": ...}
+             C4 "sift"        l2sqr_sift 1M x 128 u8, k=100, batch 4096        -> "workloads": {"sift": ...}
+           every record carries its own roofline, cpu_baseline, host_entry and a recall against an
+           INDEPENDENT exact ground truth (the reference's own sequential scan, oracle/_ref, on a query sample).
+           --workload X runs one of them alone (cos768 = one shard of C5).
+step     : one batch of queries, already resident in HBM, through the device-resident entry of the C ABI
+           (nmslib_gpu_knn_query_batch_device) on torch's current stream.  The reference-ABI entry
+           (nmslib_knn_query_batch: host pointers, PCIe inside the call) is timed beside it ("host_entry").
+N > 1    : the corpus is sharded by rows over the ranks (one process per GPU); every rank searches its shard
+           for the same batch, per-shard top-k lists are all-gathered over RCCL and merged on the GPU
+           (nmslib_gpu_merge_topk).  Total corpus fixed -> "strong".  `--gpus N` without a torchrun
+           environment launches the N ranks itself.
 
-One JSON line on stdout (rank 0).  torch is plumbing only: device buffers, streams, events,
-torch.distributed.  The CPU baseline (rank 0, N == 1) times the real reference (oracle/_ref)
-on a bounded sample of the same workload; the oracle is never part of the measured path.
+One JSON line on stdout (rank 0).  torch is plumbing only: device buffers, streams, torch.distributed.
+The CPU baseline (rank 0, N == 1) times the real reference (oracle/_ref) on a bounded sample of the same
+workload; the oracle is never part of the measured path.
 """
 import argparse
+import ctypes as C
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -26,15 +36,21 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
-import nmslib_zig_amd as nz  # noqa: E402
-from tests import refio  # noqa: E402  (synthetic data generators + recall definition only)
-
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_I8_MFMA_TOPS = 5000.0     # i8 = 2x bf16 dense (~2.5 PF) per MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0          # HBM3E spec
+
+WORKLOADS = {
+    # name: space, method, dim, batch, k, description
+    "bruteforce": dict(space="l2", method="seq_search", dim=128, batch=1024, k=10,
+                       desc="brute-force L2 1Mx128 f32 k=10 batch=1024 (BASELINE configs[1])"),
+    "hnsw": dict(space="l2", method="hnsw", dim=128, batch=1024, k=10,
+                 desc="HNSW l2 1Mx128 f32 M=16 efS={ef} k=10 batch=1024 (BASELINE configs[2])"),
+    "sift": dict(space="l2sqr_sift", method="seq_search", dim=128, batch=4096, k=100,
+                 desc="l2sqr_sift 1Mx128 u8 k=100 batch=4096 (BASELINE configs[3])"),
+    "cos768": dict(space="cosinesimil", method="hnsw", dim=768, batch=8192, k=10,
+                   desc="HNSW cosinesimil {n}x{dim} f32 M=16 efS={ef} k=10 batch={batch} (one shard of BASELINE configs[4])"),
+}
 
 
 def note(msg):
@@ -47,23 +63,25 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", choices=["bruteforce", "hnsw", "sift", "cos768"], default="bruteforce")
+    ap.add_argument("--workload", choices=["all"] + list(WORKLOADS), default="all")
     ap.add_argument("--n", type=int, default=1_000_000)
     ap.add_argument("--dim", type=int, default=None)
     ap.add_argument("--batch", type=int, default=None)
     ap.add_argument("--k", type=int, default=None)
     ap.add_argument("--ef", type=int, default=128)
+    ap.add_argument("--rank", type=int, default=64, help="cos768: latent rank of the synthetic rows")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--index-cache", default="", help="hnsw, 1 GPU: save the built index here / load it if present")
     ap.add_argument("--gpu-build", type=int, default=-1, help="hnsw: 1 = batched GPU construction, 0 = host, -1 = library default")
     ap.add_argument("--space", default="", help="bruteforce workload: another dense space (l1, linf, cosinesimil, ...)")
     ap.add_argument("--index-extra", default="", help="hnsw: extra index parameters, k=v,k=v (experiments)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="queries in the CPU baseline sample (0 = auto)")
+    ap.add_argument("--gt-sample", type=int, default=128, help="queries in the exact-ground-truth sample")
     return ap.parse_args()
 
 
 def s_768(n, dim, seed, rank=64, chunk=1 << 18):
-    """S-768: rank-64 latent + 0.1 noise, rows L2-normalised; generated in chunks."""
+    """S-768: rank-`rank` latent + 0.1 noise, rows L2-normalised; generated in chunks."""
     A = np.random.default_rng(45).standard_normal((dim, rank)).astype(np.float32)
     out = np.empty((n, dim), np.float32)
     rng = np.random.default_rng(seed)
@@ -74,14 +92,6 @@ def s_768(n, dim, seed, rank=64, chunk=1 << 18):
         x /= np.linalg.norm(x, axis=1, keepdims=True)
         out[lo:hi] = x
     return out
-
-
-def make_data(a):
-    if a.workload == "sift":
-        return refio.s_sift_like(a.n, 44), refio.s_sift_like(a.batch, 45)
-    if a.workload == "cos768":
-        return s_768(a.n, a.dim, 46), s_768(a.batch, a.dim, 47)
-    return refio.s_lowrank(a.n, a.dim, 42), refio.s_lowrank(a.batch, a.dim, 43)
 
 
 def host_threads():
@@ -96,111 +106,129 @@ def host_threads():
     return n
 
 
-def cpu_baseline(a, X, Q, gt_ids, gt_d):
-    """The reference's own code (oracle/_ref/ref_driver) on this host, all hardware threads,
-    query q on thread q mod T (Experiments::Execute protocol).  Bounded sample."""
-    from tests import orc
+class Ctx:
+    pass
+
+
+# ------------------------------------------------------------------------------------------------------------
+# The reference on the host CPU (oracle/_ref): exact ground truth for recall + the timed CPU baseline.
+# ------------------------------------------------------------------------------------------------------------
+def reference_legs(w, X, Q, ef, want_baseline, cpu_sample, gt_sample):
+    """-> (gt_ids, gt_dists, cpu_baseline dict or None, ref_ids of the baseline sample or None).
+    gt_* = the reference's exact sequential scan at k+22 on the first gt_sample queries (tie-extended recall needs
+    more than k entries).  The baseline = the reference's own method for this workload, all hardware threads,
+    query q on thread q mod T (Experiments::Execute protocol), on a bounded sample."""
+    from tests import orc, refio
     cores = host_threads()
-    space = {"sift": "l2sqr_sift", "cos768": "cosinesimil"}.get(a.workload, "l2")
-    if a.workload in ("hnsw", "cos768"):
-        method, ip, qp = "hnsw", f"M=16,efConstruction=200,indexThreadQty={cores}", f"efSearch={a.ef}"
-        ns = a.cpu_sample or min(Q.shape[0], 1024)
-    else:
-        method, ip, qp = "seq_search", "", ""
-        ns = a.cpu_sample or min(Q.shape[0], max(64, 32 * cores))  # ~20-30 s of CPU work at 1M rows
-    Qs = Q[:ns]
-    t0 = time.time()
-    if refio.HAVE_REF:
-        ids, d, cnt, ndc, info = refio.run_ref_driver(space, method, X, Qs, a.k, ip, qp, threads=cores, repeat=1)
-        kind, qps, used = "reference", info["qps"], cores
-        extra = {"build_s": info["build_s"]} if method == "hnsw" else {}
-    else:
-        # oracle/_ref was not shipped: time this repo's scalar restatement instead (1 thread)
-        ns = min(ns, 8)
-        Qs = Q[:ns]
+    space, k = w["space"], w["k"]
+    ngt = min(gt_sample, Q.shape[0])
+    if not refio.HAVE_REF:
+        # oracle/_ref was not shipped: this repo's scalar restatement (1 thread) on a handful of queries
+        ngt = min(ngt, 8)
         t1 = time.time()
-        ids, d, _ = orc.seq_search(space, X, Qs, a.k)
-        kind, qps, used, extra = "port", ns / (time.time() - t1), 1, {}
-    rec = None
-    if gt_ids is not None:
-        m = min(ns, len(gt_ids))
-        gd = gt_d[:m] ** 2 if (a.workload == "hnsw") else gt_d[:m]   # HNSW-l2 returns squared L2
-        rec = refio.recall_nmslib(ids[:m], gt_ids[:m], gd, a.k, integer=(a.workload == "sift"))
-    out = {"value": round(float(qps), 2), "unit": "queries/s", "cores": used, "kind": kind,
-           "sample": f"{ns} of the {Q.shape[0]} queries against all {X.shape[0]} rows, method={method}"
-                     + (f", {qp}" if qp else "") + f", {used} threads",
-           "wall_s": round(time.time() - t0, 1)}
-    if rec is not None:
-        out["recall_at_k"] = round(float(rec), 4)
-    out.update(extra)
-    return out
+        gi, gd, _ = orc.seq_search(space, X, Q[:ngt], min(k + 22, X.shape[0]))
+        base = None
+        if want_baseline:
+            base = {"value": round(ngt / (time.time() - t1), 2), "unit": "queries/s", "cores": 1, "kind": "port",
+                    "sample": f"{ngt} of the {Q.shape[0]} queries against all {X.shape[0]} rows, exact scan (oracle port; "
+                              "oracle/_ref not shipped)"}
+        return gi, gd, base
+    tmp = tempfile.mkdtemp(prefix="bench_ref_")
+    try:
+        note(f"reference exact scan for the ground truth ({ngt} queries, {cores} threads)")
+        gi, gd, _, _, _ = refio.run_ref_driver(space, "seq_search", X, Q[:ngt], min(k + 22, X.shape[0]), "", "",
+                                               threads=cores, workdir=tmp)
+        base = None
+        if want_baseline:
+            t0 = time.time()
+            if w["method"] == "hnsw":
+                ip, qp = f"M=16,efConstruction=200,indexThreadQty={cores}", f"efSearch={ef}"
+                ns = cpu_sample or min(Q.shape[0], 1024)
+                rep = 3
+            else:
+                ip, qp = "", ""
+                # ~10-30 s of CPU work: the reference scans ~25 (f32) / ~80 (u8) queries/s/thread at 1M rows
+                per_thr = 80 if space == "l2sqr_sift" else 25
+                ns = cpu_sample or min(Q.shape[0], max(64, int(per_thr * cores * 15 * 1e6 / max(X.shape[0], 1))))
+                rep = 1
+            note(f"timing the CPU baseline: reference {w['method']} on {ns} queries, {cores} threads")
+            ids, d, cnt, ndc, info = refio.run_ref_driver(space, w["method"], X, Q[:ns], k, ip, qp, threads=cores,
+                                                          repeat=rep, workdir=tmp)
+            m = min(ns, ngt)
+            gdd = gd[:m] ** 2 if (w["method"] == "hnsw" and space == "l2") else gd[:m]   # HNSW-l2 returns squared L2
+            rec = refio.recall_nmslib(ids[:m], gi[:m], gdd, k, integer=(space == "l2sqr_sift"))
+            base = {"value": round(float(info["qps"]), 2), "unit": "queries/s", "cores": cores, "kind": "reference",
+                    "sample": f"{ns} of the {Q.shape[0]} queries against all {X.shape[0]} rows, method={w['method']}"
+                              + (f", {qp}" if qp else "") + f", {cores} threads, best of {rep}",
+                    "recall_at_k": round(float(rec), 4), "wall_s": round(time.time() - t0, 1)}
+            if w["method"] == "hnsw":
+                base["build_s"] = info["build_s"]
+        return gi, gd, base
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
-def main():
-    a = parse()
-    rank = int(os.environ.get("RANK", 0))
-    world = int(os.environ.get("WORLD_SIZE", 1))
-    local = int(os.environ.get("LOCAL_RANK", 0))
-    if a.dim is None:
-        a.dim = 768 if a.workload == "cos768" else 128
-    if a.batch is None:
-        a.batch = {"sift": 4096, "cos768": 8192}.get(a.workload, 1024)
-    if a.workload == "cos768":
-        a.no_cpu_baseline = a.no_cpu_baseline or a.n > 200_000   # the reference's 768-D build takes too long beyond that
-    if a.k is None:
-        a.k = 100 if a.workload == "sift" else 10
-    torch.cuda.set_device(local % max(1, torch.cuda.device_count()))
-    os.environ.setdefault("NMSLIB_GPU_DEVICE", str(torch.cuda.current_device()))
-    dev = torch.device("cuda", torch.cuda.current_device())
-    # BENCH_BACKEND=gloo: rehearsal of the multi-rank protocol on ONE GPU (RCCL refuses two ranks on a device): the
-    # collective then goes through host memory; everything else (shards, packed layout, strided merge) is the real path
-    backend = os.environ.get("BENCH_BACKEND", "nccl")
-    if world > 1:
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)   # RCCL over xGMI
-        else:
-            dist.init_process_group(backend)
+# ------------------------------------------------------------------------------------------------------------
+def run_workload(a, name, cx):
+    import torch
+    import torch.distributed as dist
+    import nmslib_zig_amd as nz
+    from tests import refio
 
-    note(f"generating data: workload={a.workload} n={a.n}")
-    X, Q = make_data(a)
-    n, nq, k = X.shape[0], Q.shape[0], a.k
+    w = dict(WORKLOADS[name])
+    single = a.workload != "all"
+    n = a.n
+    if single:
+        w["dim"] = a.dim or w["dim"]
+        w["batch"] = a.batch or w["batch"]
+        w["k"] = a.k or w["k"]
+        if a.space and name == "bruteforce":
+            w["space"] = a.space
+    space, method, dim, nq, k = w["space"], w["method"], w["dim"], w["batch"], w["k"]
+    u8 = space == "l2sqr_sift"
+    rank, world, dev = cx.rank, cx.world, cx.dev
+
+    note(f"[{name}] generating data: n={n} dim={dim}")
+    if name == "sift":
+        X, Q = refio.s_sift_like(n, 44), refio.s_sift_like(nq, 45)
+    elif name == "cos768":
+        X, Q = s_768(n, dim, 46, a.rank), s_768(nq, dim, 47, a.rank)
+    else:
+        X, Q = refio.s_lowrank(n, dim, 42), refio.s_lowrank(nq, dim, 43)   # SURVEY.md 8d
     lo, hi = rank * n // world, (rank + 1) * n // world          # this rank's row shard
-    u8 = a.workload == "sift"
-    space = "l2sqr_sift" if u8 else ("cosinesimil" if a.workload == "cos768" else "l2")
-    if a.space and a.workload == "bruteforce":
-        space = a.space
-    method = "hnsw" if a.workload in ("hnsw", "cos768") else "seq_search"
-    cache = a.index_cache if (method == "hnsw" and world == 1) else ""
+    cache = a.index_cache if (method == "hnsw" and world == 1 and single) else ""
+    build_kw = {"gpu_build": a.gpu_build} if a.gpu_build >= 0 else {}
+    build_kw.update(dict(kv.split("=") for kv in a.index_extra.split(",") if kv))
     t_build = time.time()
+    graph_build_s = None
     if cache and os.path.exists(cache):
         note(f"loading cached index {cache}")
         idx = nz.Index.load(cache, load_data=False)              # the reference's optimized-index format
         idx.finalize()
-        idx.setQueryTimeParams(efSearch=a.ef)
     else:
         idx = nz.Index(space, method, data_type="DenseUInt8Vector" if u8 else "DenseVector",
                        dist_type="Int" if u8 else "Float")
-        ids = np.arange(lo, hi, dtype=np.int32)                      # external id = global row
+        ids = np.arange(lo, hi, dtype=np.int32)                  # external id = global row
         (idx.addUInt8Batch if u8 else idx.addDenseBatch)(X[lo:hi], ids)
-        note("building index (rows -> HBM" + (", HNSW construction" if method == "hnsw" else "") + ")")
         if method == "hnsw":
-            extra = dict(kv.split("=") for kv in a.index_extra.split(",") if kv)
-            idx.buildIndex(M=16, efConstruction=200, **({"gpu_build": a.gpu_build} if a.gpu_build >= 0 else {}), **extra)
-            note(f"graph built in {idx.stats()['build_seconds']:.2f}s")
-            idx.setQueryTimeParams(efSearch=a.ef)
+            idx.buildIndex(M=16, efConstruction=200, **build_kw)
+            graph_build_s = idx.stats()["build_seconds"]
+            note(f"[{name}] graph built in {graph_build_s:.2f}s")
             if cache:
                 idx.save(cache, False)
         else:
             idx.buildIndex()
+    if method == "hnsw":
+        idx.setQueryTimeParams(efSearch=a.ef)
     t_build = time.time() - t_build
-    note(f"index ready in {t_build:.1f}s; timing {a.steps} steps")
+    note(f"[{name}] index ready in {t_build:.1f}s; timing {a.steps} steps")
 
     dq = torch.from_numpy(Q).to(dev)
     pack = torch.empty((2, nq, k), dtype=torch.int32, device=dev)    # ids | distance bits: one collective moves both
     d_ids, d_ds = pack[0], pack[1].view(torch.float32)
     d_cnt = torch.empty((nq,), dtype=torch.int32, device=dev)
     if world > 1:
-        g_pack = torch.empty((world * 2, nq, k), dtype=torch.int32, device=dev)   # [world][2][nq][k], concatenated form
+        g_pack = torch.empty((world * 2, nq, k), dtype=torch.int32, device=dev)   # [world][2][nq][k]
         m_ids = torch.empty((nq, k), dtype=torch.int32, device=dev)
         m_ds = torch.empty((nq, k), dtype=torch.float32, device=dev)
     stream = torch.cuda.current_stream()
@@ -209,7 +237,7 @@ def main():
         idx.knn_device(dq.data_ptr(), nq, Q.shape[1], k, d_ids.data_ptr(), d_ds.data_ptr(), d_cnt.data_ptr(),
                        stream.cuda_stream)
         if world > 1:
-            if backend == "nccl":
+            if cx.backend == "nccl":
                 dist.all_gather_into_tensor(g_pack, pack)
             else:
                 g_host = torch.empty(g_pack.shape, dtype=g_pack.dtype)
@@ -242,49 +270,17 @@ def main():
     res_ids = (m_ids if world > 1 else d_ids).cpu().numpy()
     res_ds = (m_ds if world > 1 else d_ds).cpu().numpy()
     counters = idx.read_counters(nq) if method == "hnsw" else None
-
     if rank != 0:
-        if world > 1:
-            dist.destroy_process_group()
-        return
+        idx.close()
+        return None
 
-    # ---- ground truth for recall (exact k-NN; tie-extended per NMSLIB's definition) ----------
-    gt_ids = gt_d = None
-    recall = None
-    if world > 1 and backend != "nccl" and method != "hnsw":
-        # rehearsal only: the merged result of the shards against one exact scan of the whole corpus
-        full = nz.Index(space, "seq_search", data_type="DenseUInt8Vector" if u8 else "DenseVector",
-                        dist_type="Int" if u8 else "Float")
-        (full.addUInt8Batch if u8 else full.addDenseBatch)(X)
-        full.buildIndex()
-        f_ids, f_ds, _ = full.knnQueryBatch(Q, k)
-        full.close()
-        recall = float((f_ids == res_ids).mean())
-        assert np.array_equal(f_ds, res_ds), "sharded + merged distances differ from the unsharded scan"
-    if world == 1:
-        if method == "hnsw":
-            ngt = nq if a.workload == "hnsw" else min(nq, 256)
-            idx.close()                                                        # free the HBM copy first
-            bf = nz.Index(space, "seq_search")
-            bf.addDenseBatch(X)
-            bf.buildIndex()
-            gt_ids, gt_d, _ = bf.knnQueryBatch(Q[:ngt], k + 22)
-            bf.close()
-            # HNSW-l2 returns squared L2; cosine distances are the same on both paths
-            recall = refio.recall_nmslib(res_ids[:ngt], gt_ids, gt_d ** 2 if space == "l2" else gt_d, k)
-        else:
-            # brute force IS the exact method; its recall against itself at k+22 checks the tie rule
-            gt_ids, gt_d, _ = idx.knnQueryBatch(Q[:64], min(k + 22, 512))
-            recall = refio.recall_nmslib(res_ids[:64], gt_ids, gt_d, k, integer=u8)
-
-    # ---- roofline of the dominant kernel ---------------------------------------------------------
+    # ---- roofline of the dominant kernel (this rank's launches; HIP events on the launch stream) ---------
     kern_s = kern_ms / 1e3 / max(1, launches)
     rows_local = hi - lo
     if method == "hnsw":
         ndc, hops, hops_up = (c.astype(np.float64) for c in counters)
-        D = Q.shape[1]
         # bytes/query = ndc*D*4 + hops0*(maxM0+1)*4 + hops_up*(maxM+1)*4 + ndc (visited)
-        alg_bytes = float((ndc * D * 4 + hops * 33 * 4 + hops_up * 17 * 4 + ndc).sum())
+        alg_bytes = float((ndc * dim * 4 + hops * 33 * 4 + hops_up * 17 * 4 + ndc).sum())
         roof = {"bound": "hbm", "achieved": round(alg_bytes / kern_s / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                 "kernel": "hnsw_search_kernel", "ndc_per_query": round(float(ndc.mean()), 1),
                 "hops_per_query": round(float(hops.mean()), 1)}
@@ -293,23 +289,26 @@ def main():
         roof = {"bound": "mfma", "achieved": round(ops / kern_s / 1e12, 2), "peak": PEAK_I8_MFMA_TOPS, "unit": "TOP/s",
                 "kernel": "bf_select_u8_kernel"}
     else:
-        flops = 2.0 * nq * rows_local * Q.shape[1]             # 2*Q*N*D
+        flops = 2.0 * nq * rows_local * dim             # 2*Q*N*D
         roof = {"bound": "mfma", "achieved": round(flops / kern_s / 1e12, 2), "peak": PEAK_F32_MFMA_TFLOPS,
                 "unit": "TFLOP/s", "kernel": "bf_select_f32_kernel"}
     roof["frac"] = round(roof["achieved"] / roof["peak"], 4)
     roof["kernel_ms"] = round(kern_s * 1e3, 4)
     roof["traffic"] = None
-    tr = os.path.join(ROOT, "profiles", "traffic.json")       # PMC-measured HBM bytes/launch, if collected
-    if os.path.exists(tr):
+    tr = os.path.join(ROOT, "profiles", "traffic.json")   # HBM bytes/launch from a separate rocprofv3 --pmc pass
+    if os.path.exists(tr) and n == 1_000_000 and world == 1 and dim == WORKLOADS[name]["dim"] and not a.space:
         try:
-            roof["traffic"] = json.load(open(tr)).get(a.workload) if (a.n == 1_000_000 and world == 1 and a.dim in (128, 768) and not (a.workload == "bruteforce" and a.dim != 128)) else None
+            tj = json.load(open(tr))
+            roof["traffic"] = tj.get(name)
+            roof["traffic_source"] = tj.get("source")
         except Exception:
             pass
 
     out = {
         "metric": {"sift": f"queries/sec @ recall@{k}, {n} x 128-D u8 l2sqr_sift, batch={nq}",
-                   "cos768": f"queries/sec @ recall@{k}, {n} x {Q.shape[1]}-D cosinesimil HNSW, batch={nq}"}.get(
-                       a.workload, "queries/sec @ recall@10, 1M x 128-D L2, batch=1024"),
+                   "hnsw": f"queries/sec @ recall@{k}, {n} x {dim}-D L2 HNSW, batch={nq}; HBM GB/s vs peak",
+                   "cos768": f"queries/sec @ recall@{k}, {n} x {dim}-D cosinesimil HNSW, batch={nq}"}.get(
+                       name, "queries/sec @ recall@10, 1M x 128-D L2, batch=1024; HBM GB/s vs peak"),
         "value": round(a.steps * nq / elapsed, 1),
         "unit": "queries/s",
         "n_gpus": world,
@@ -322,25 +321,23 @@ def main():
         "dtype": "u8" if u8 else "f32",
         "data": "synthetic",
         "config": {
-            "workload": {"bruteforce": "brute-force L2 1Mx128 f32 k=10 batch=1024 (BASELINE configs[1])",
-                         "hnsw": f"HNSW l2 1Mx128 f32 M=16 efS={a.ef} k=10 batch=1024 (BASELINE configs[2])",
-                         "sift": "l2sqr_sift 1Mx128 u8 k=100 batch=4096 (BASELINE configs[3])",
-                         "cos768": f"HNSW cosinesimil {n}x{Q.shape[1]} f32 M=16 efS={a.ef} k=10 batch={nq} "
-                                   "(one shard of BASELINE configs[4])"}[a.workload],
-            "rows": n, "dim": int(Q.shape[1]), "batch": nq, "k": k, "rows_per_gpu": rows_local,
-            "dataset": "S-sift-like seeds 44/45" if u8 else ("S-768 rank-64 + 0.1 noise, unit rows, seeds 46/47"
-                                                             if a.workload == "cos768" else
+            "workload": w["desc"].format(ef=a.ef, n=n, dim=dim, batch=nq),
+            "rows": n, "dim": dim, "batch": nq, "k": k, "rows_per_gpu": rows_local,
+            "dataset": "S-sift-like seeds 44/45" if u8 else (f"S-768 rank-{a.rank} + 0.1 noise, unit rows, seeds 46/47"
+                                                             if name == "cos768" else
                                                              "S-lowrank rank-16 + 0.1 noise, seeds 42/43"),
-            "sharding": f"rows/{world} + RCCL all-gather of per-shard top-k" if world > 1 else "single GPU",
+            "sharding": (f"rows/{world} + {'RCCL' if cx.backend == 'nccl' else cx.backend} all-gather of per-shard top-k"
+                         if world > 1 else "single GPU"),
+            "entry": "nmslib_gpu_knn_query_batch_device (queries and results resident in HBM)",
             "build_s": round(t_build, 2),
         },
-        "recall_at_k": None if recall is None else round(float(recall), 4),
         "roofline": roof,
     }
-    if world == 1 and a.workload != "cos768":
-        # the reference's own host-pointer entry (nmslib_knn_query_batch): H2D of the batch + D2H of the results inside
-        # the call.  Reported beside the device-resident number, never as `value`.
-        import ctypes as C
+    if graph_build_s is not None:
+        out["config"]["graph_build_s"] = round(graph_build_s, 2)
+
+    # ---- the reference-ABI entry: nmslib_knn_query_batch, host pointers, PCIe inside the call --------------
+    if world == 1:
         h_ids = np.empty((nq, k), np.int32)
         h_ds = np.empty((nq, k), np.float32)
         res = (nz.Result * nq)()
@@ -348,11 +345,6 @@ def main():
             res[i] = nz.Result(h_ids[i].ctypes.data_as(C.POINTER(C.c_int32)), h_ds[i].ctypes.data_as(C.POINTER(C.c_float)), 0, k)
         hsteps = max(3, min(a.steps, 10))
         L = nz.lib()
-        if method == "hnsw":                      # (the HNSW index was closed for the ground-truth pass: rebuild it)
-            idx = nz.Index(space, method)
-            idx.addDenseBatch(X[lo:hi], np.arange(lo, hi, dtype=np.int32))
-            idx.buildIndex(M=16, efConstruction=200, **({"gpu_build": a.gpu_build} if a.gpu_build >= 0 else {}))
-            idx.setQueryTimeParams(efSearch=a.ef)
         nz._check(L.nmslib_knn_query_batch(idx.h, Q.ctypes.data, nq, Q.shape[1], k, res, None, 0))
         th = time.perf_counter()
         for _ in range(hsteps):
@@ -361,14 +353,73 @@ def main():
         out["host_entry"] = {"entry": "nmslib_knn_query_batch (host pointers, PCIe inside the call)",
                              "ms_per_step": round(th * 1e3, 4), "queries_per_s": round(nq / th, 1),
                              "matches_device_entry": bool(np.array_equal(h_ids, res_ids))}
-    if world == 1 and not a.no_cpu_baseline:
-        note("timing the CPU baseline (oracle/_ref) on a bounded sample")
-        try:
-            out["cpu_baseline"] = cpu_baseline(a, X, Q, gt_ids, gt_d)
-        except Exception as e:  # the baseline must never take the GPU number down with it
-            out["cpu_baseline"] = {"value": None, "unit": "queries/s", "cores": 0, "kind": "reference",
-                                   "sample": f"failed: {e}"}
-    print(json.dumps(out))
+    idx.close()
+
+    # ---- recall against an independent exact ground truth + the CPU baseline ---------------------------------
+    # (cos768 beyond 200k rows: the reference's 768-D build takes too long for a bench run; exact scan only)
+    want_base = world == 1 and not a.no_cpu_baseline and not (name == "cos768" and n > 200_000)
+    try:
+        gt_ids, gt_d, base = reference_legs(w, X, Q, a.ef, want_base, a.cpu_sample, a.gt_sample)
+        m = len(gt_ids)
+        gdd = gt_d ** 2 if (method == "hnsw" and space == "l2") else gt_d      # HNSW-l2 returns squared L2
+        out["recall_at_k"] = round(float(refio.recall_nmslib(res_ids[:m], gt_ids, gdd, k, integer=u8)), 4)
+        out["recall_ground_truth"] = f"reference seq_search (oracle/_ref), exact, first {m} queries, tie-extended at k+22"
+        if method != "hnsw":
+            # the exact method must also reproduce the reference's distances on the sample (1e-5 rel; integers exact)
+            ok = np.array_equal(res_ds[:m], gt_d[:, :k]) if u8 else np.allclose(res_ds[:m], gt_d[:, :k], rtol=1e-5, atol=1e-6)
+            out["distances_match_reference"] = bool(ok)
+        if base is not None:
+            out["cpu_baseline"] = base
+    except Exception as e:  # the baseline must never take the GPU number down with it
+        out["recall_at_k"] = None
+        out["cpu_baseline"] = {"value": None, "unit": "queries/s", "cores": 0, "kind": "reference", "sample": f"failed: {e}"}
+    return out
+
+
+def main():
+    a = parse()
+    # --gpus N without a torchrun environment: launch the N ranks ourselves (before anything touches the GPU)
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        port = 29500 + (os.getpid() % 2000)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    if world != a.gpus:
+        print(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: refusing to report a mismatched n_gpus", file=sys.stderr)
+        sys.exit(2)
+
+    import torch
+    import torch.distributed as dist
+    cx = Ctx()
+    cx.rank, cx.world = rank, world
+    torch.cuda.set_device(local % max(1, torch.cuda.device_count()))
+    os.environ.setdefault("NMSLIB_GPU_DEVICE", str(torch.cuda.current_device()))
+    cx.dev = torch.device("cuda", torch.cuda.current_device())
+    # BENCH_BACKEND=gloo: rehearsal of the multi-rank protocol on ONE GPU (RCCL refuses two ranks on a device): the
+    # collective then goes through host memory; everything else (shards, packed layout, strided merge) is the real path
+    cx.backend = os.environ.get("BENCH_BACKEND", "nccl")
+    if world > 1:
+        if cx.backend == "nccl":
+            dist.init_process_group("nccl", device_id=cx.dev)   # RCCL over xGMI
+        else:
+            dist.init_process_group(cx.backend)
+
+    if a.workload == "all":
+        out = run_workload(a, "bruteforce", cx)
+        subs = {}
+        for name in ("hnsw", "sift"):
+            r = run_workload(a, name, cx)
+            if r is not None:
+                subs[name] = r
+        if out is not None:
+            out["workloads"] = subs
+    else:
+        out = run_workload(a, a.workload, cx)
+    if rank == 0:
+        print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
 

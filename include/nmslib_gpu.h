@@ -79,6 +79,7 @@ typedef struct {
     size_t hbm_bytes;        /* bytes resident in HBM for this index   */
     size_t rows;
     size_t dim;
+    size_t shards;         /* row shards behind this handle (index parameter gpu_shards); 1 = single GPU */
 } nmslib_gpu_stats_t;
 nmslib_error_t nmslib_gpu_get_stats(nmslib_index_handle_t index, nmslib_gpu_stats_t* out);
 

@@ -692,6 +692,7 @@ nmslib_error_t nmslib_gpu_get_stats(nmslib_index_handle_t handle, nmslib_gpu_sta
     out->hbm_bytes = e->hbm_bytes();
     out->rows = e->size();
     out->dim = e->dim();
+    out->shards = e->shard_count() ? e->shard_count() : 1;
     return NMSLIB_SUCCESS;
 }
 

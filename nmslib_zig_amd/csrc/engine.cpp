@@ -135,6 +135,8 @@ Engine::~Engine() {
         (void)hipEventDestroy(pr.first);
         (void)hipEventDestroy(pr.second);
     }
+    for (hipEvent_t e : shard_events_) (void)hipEventDestroy(e);
+    if (shard_ready_) (void)hipEventDestroy(shard_ready_);
     if (stream_) (void)hipStreamDestroy(stream_);
 }
 
@@ -213,6 +215,9 @@ void Engine::reset() {
     dirty_ = true;
     graph_dirty_ = true;
     d_n_ = 0;
+    shards_.clear();
+    dim_ = 0;  // a reset index accepts rows of another dimension
+    centred_ = false;
 }
 
 size_t Engine::memory_usage() const {
@@ -224,8 +229,10 @@ size_t Engine::memory_usage() const {
 }
 
 size_t Engine::hbm_bytes() const {
-    return d_rows_.bytes() + d_rows_i8_.bytes() + d_aux_.bytes() + d_ids_.bytes() + d_links0_.bytes() + d_up_off_.bytes() +
-           d_up_links_.bytes() + d_rownorm_.bytes();
+    size_t sh = 0;
+    for (const auto& c : shards_) sh += c->hbm_bytes();
+    return sh + d_rows_.bytes() + d_rows_i8_.bytes() + d_aux_.bytes() + d_ids_.bytes() + d_links0_.bytes() + d_up_off_.bytes() +
+           d_up_links_.bytes() + d_rownorm_.bytes() + d_rows_sel_.bytes();
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -256,6 +263,8 @@ void Engine::create_index(const std::vector<std::string>& params) {
         ps.get("gpu_defer", defer);  // engine extension: build now, upload to HBM at first use
         ps.get("gpu_build", bp.gpu_build);  // engine extension: batched construction on the GPU (1), host (0)
         ps.get("gpu_build_batch", bp.gpu_build_batch);
+        ps.get("gpu_build_div", bp.gpu_build_div);
+        ps.get("gpu_shards", gpu_shards_);  // engine extension: row shards over the visible GPUs (0 = all)
         ps.check_unused();
         if (defer && bp.gpu_build < 0) bp.gpu_build = 0;  // deferred upload = no device work now
         bp_ = bp;
@@ -269,6 +278,7 @@ void Engine::create_index(const std::vector<std::string>& params) {
         ps.get("multiThread", multi);
         ps.get("threadQty", thread_qty);
         ps.get("gpu_defer", defer);
+        ps.get("gpu_shards", gpu_shards_);
         ps.check_unused();
     } else {
         throw EngineError(Err::IndexBuildFailed,
@@ -326,7 +336,8 @@ void Engine::check_device() {
                           "(there is no CPU fallback)");
     }
     int dev = 0;
-    if (const char* env = getenv("NMSLIB_GPU_DEVICE")) dev = atoi(env);
+    if (forced_device_ >= 0) dev = forced_device_ % count;
+    else if (const char* env = getenv("NMSLIB_GPU_DEVICE")) dev = atoi(env);
     else if (const char* lr = getenv("LOCAL_RANK")) dev = atoi(lr) % count;
     hip_check(hipSetDevice(dev), "hipSetDevice");
     device_ = dev;
@@ -334,16 +345,16 @@ void Engine::check_device() {
 }
 
 void Engine::upload_rows() {
-    const size_t n = ids_.size();
+    const size_t n = size();
     auto t0 = clk::now();
     if (is_u8()) {
         ldb_ = 128;
         d_rows_.ensure(std::max<size_t>(n, 1) * 128);
-        if (n) hip_check(hipMemcpy(d_rows_.ptr(), rows_u8_.data(), n * 128, hipMemcpyHostToDevice), "upload rows");
+        if (n) hip_check(hipMemcpy(d_rows_.ptr(), rows_u8(), n * 128, hipMemcpyHostToDevice), "upload rows");
     } else {
         ldb_ = f32_row_stride((int)dim_);
         d_rows_.ensure(std::max<size_t>(n, 1) * ldb_ * 4);
-        const float* src = rows_f32_.data();
+        const float* src = rows_f32();
         if (loaded_graph_ && !graph_rows_.empty()) src = graph_rows_.data();
         if (n) {
             hip_check(hipMemset(d_rows_.ptr(), 0, n * ldb_ * 4), "clear rows");
@@ -352,7 +363,15 @@ void Engine::upload_rows() {
         }
     }
     d_ids_.ensure(std::max<size_t>(n, 1) * 4);
-    if (n) hip_check(hipMemcpy(d_ids_.ptr(), ids_.data(), n * 4, hipMemcpyHostToDevice), "upload ids");
+    if (parent_) {
+        // shard child: results carry GLOBAL positions; the parent maps them to external ids after the merge, so
+        // that ties are ordered exactly as in the unsharded index (distance, position)
+        std::vector<int32_t> pos(n);
+        for (size_t i = 0; i < n; ++i) pos[i] = (int32_t)(view_lo_ + i);
+        if (n) hip_check(hipMemcpy(d_ids_.ptr(), pos.data(), n * 4, hipMemcpyHostToDevice), "upload positions");
+    } else if (n) {
+        hip_check(hipMemcpy(d_ids_.ptr(), ids_.data(), n * 4, hipMemcpyHostToDevice), "upload ids");
+    }
     d_n_ = n;
     upload_seconds = std::chrono::duration<double>(clk::now() - t0).count();
 }
@@ -360,15 +379,15 @@ void Engine::upload_rows() {
 void Engine::build_graph() {
     auto t0 = clk::now();
     if (!loaded_graph_) {
-        const void* rows = is_u8() ? static_cast<const void*>(rows_u8_.data()) : static_cast<const void*>(rows_f32_.data());
-        hnsw_build_host(space_, rows, ids_.size(), dim_, bp_, graph_);
+        const void* rows = is_u8() ? static_cast<const void*>(rows_u8()) : static_cast<const void*>(rows_f32());
+        hnsw_build_host(space_, rows, size(), dim_, bp_, graph_);
     }
     build_seconds = std::chrono::duration<double>(clk::now() - t0).count();
 }
 
 void Engine::prepare_graph_rows() {
     // search-time distance of the flat ("optimized") index, hnsw.cc:369-412
-    const size_t n = ids_.size();
+    const size_t n = size();
     int sspace = space_;
     bool normalize = false;
     const bool optimized = !bp_.skip_optimized;
@@ -386,7 +405,8 @@ void Engine::prepare_graph_rows() {
         std::vector<int32_t> norms(n);
         for (size_t i = 0; i < n; ++i) {
             int32_t s = 0;
-            for (int t = 0; t < 128; ++t) s += (int32_t)rows_u8_[i * 128 + t] * (int32_t)rows_u8_[i * 128 + t];
+            const uint8_t* r8 = rows_u8() + i * 128;
+            for (int t = 0; t < 128; ++t) s += (int32_t)r8[t] * (int32_t)r8[t];
             norms[i] = s;
         }
         if (n) hip_check(hipMemcpy(d_rownorm_.ptr(), norms.data(), n * 4, hipMemcpyHostToDevice), "row norms");
@@ -441,7 +461,7 @@ bool Engine::use_gpu_build() const {
 // closes its batch.  All searches of a batch (every level, top down) precede all link updates.
 void Engine::build_graph_gpu() {
     auto t0 = clk::now();
-    const size_t n = ids_.size();
+    const size_t n = size();
     hnsw_check_params(bp_);
     const int M = bp_.M, maxM = bp_.maxM, maxM0 = bp_.maxM0, efC = bp_.efConstruction;
     if (efC < 1 || efC > 1024)
@@ -485,20 +505,27 @@ void Engine::build_graph_gpu() {
     bgraph.ext_ids = nullptr;  // construction works on internal positions
     int maxlevel = g.levels[0], enterpoint = 0;
     const int max_batch = bp_.gpu_build_batch > 0 ? bp_.gpu_build_batch : 4096;
-    const int req_cap = 32;
-    wb_req_cnt_.ensure(n * 4);
-    wb_req_node_.ensure(n * (size_t)req_cap * 4);
-    wb_req_dist_.ensure(n * (size_t)req_cap * 4);
-    wb_active_.ensure(n * 4);
+    const int batch_div = bp_.gpu_build_div > 0 ? bp_.gpu_build_div : 16;
+    // reverse-link requests of one level of one batch: M slots per new node, sorted on the device
+    const size_t req_max = (size_t)max_batch * (size_t)M;
+    wb_req_key_.ensure(req_max * 8);
+    wb_req_dist_.ensure(req_max * 4);
+    wb_req_key2_.ensure(req_max * 8);
+    wb_req_dist2_.ensure(req_max * 4);
+    const size_t sort_tmp = hnsw_build_sort_temp_bytes((int)req_max, (int)n);
+    wb_sort_tmp_.ensure(sort_tmp);
+    wb_active_.ensure(req_max * 4);
     wb_nactive_.ensure(64);
-    hip_check(hipMemsetAsync(wb_req_cnt_.ptr(), 0, n * 4, s), "clear requests");
+    wb_extra_ids_.ensure((size_t)max_batch * 64 * 4);  // batch-mates: 64 per new node of a level slice
+    wb_extra_d_.ensure((size_t)max_batch * 64 * 4);
+    wb_extra_n_.ensure((size_t)max_batch * 4);
 
     std::vector<int32_t> pts, src, status;
     std::vector<size_t> base;
     size_t next = 1;
     while (next < n) {
         const size_t sz = next;
-        size_t bsz = std::min<size_t>(std::max<size_t>(sz / 16, 1), (size_t)max_batch);
+        size_t bsz = std::min<size_t>(std::max<size_t>(sz / (size_t)batch_div, 1), (size_t)max_batch);
         size_t end = std::min(n, next + bsz);
         for (size_t i = next; i < end; ++i)
             if (g.levels[i] > maxlevel) {
@@ -584,17 +611,25 @@ void Engine::build_graph_gpu() {
         for (int l = top; l >= 0; --l) {
             const size_t b0 = base[l], m = slice_end(l) - b0;
             if (m == 0) continue;
-            hip_check(hipMemsetAsync(wb_nactive_.ptr(), 0, 4, s), "clear active count");
+            const int total = (int)(m * (size_t)M);
+            hip_check(launch_hnsw_build_mates(bg, l, wb_pts_.as<int32_t>() + b0, (int)m, wb_cand_d_.as<float>() + b0 * efC,
+                                              wb_cand_n_.as<int32_t>() + b0, efC, wb_extra_ids_.as<int32_t>(),
+                                              wb_extra_d_.as<float>(), wb_extra_n_.as<int32_t>(), s),
+                      "build batch-mates");
             hip_check(launch_hnsw_build_select(bg, l, wb_pts_.as<int32_t>() + b0, (int)m,
                                                wb_cand_ids_.as<int32_t>() + b0 * efC, wb_cand_d_.as<float>() + b0 * efC,
-                                               wb_cand_n_.as<int32_t>() + b0, efC, wb_req_cnt_.as<int32_t>(),
-                                               wb_req_node_.as<int32_t>(), wb_req_dist_.as<float>(), req_cap,
-                                               wb_active_.as<int32_t>(), wb_nactive_.as<int32_t>(), s),
+                                               wb_cand_n_.as<int32_t>() + b0, efC, wb_extra_ids_.as<int32_t>(),
+                                               wb_extra_d_.as<float>(), wb_extra_n_.as<int32_t>(),
+                                               wb_req_key_.as<unsigned long long>(), wb_req_dist_.as<float>(), s),
                       "build select");
-            const size_t max_active = std::min<size_t>(sz, m * (size_t)M);
+            hip_check(launch_hnsw_build_sort_requests(wb_req_key_.as<unsigned long long>(), wb_req_dist_.as<float>(), total,
+                                                      wb_req_key2_.as<unsigned long long>(), wb_req_dist2_.as<float>(),
+                                                      wb_sort_tmp_.ptr(), sort_tmp, wb_active_.as<int32_t>(),
+                                                      wb_nactive_.as<int32_t>(), s),
+                      "build sort");
+            const size_t max_active = std::min<size_t>(sz, (size_t)total);
             hip_check(launch_hnsw_build_link(bg, l, wb_active_.as<int32_t>(), wb_nactive_.as<int32_t>(), (int)max_active,
-                                             wb_req_cnt_.as<int32_t>(), wb_req_node_.as<int32_t>(),
-                                             wb_req_dist_.as<float>(), req_cap, s),
+                                             wb_req_key2_.as<unsigned long long>(), wb_req_dist2_.as<float>(), total, s),
                       "build link");
         }
         for (size_t i = next; i < end; ++i)
@@ -618,14 +653,14 @@ void Engine::build_graph_gpu() {
     dg_.maxlevel = maxlevel;
     dg_.enterpoint = enterpoint;
     for (DevBuf* b : {&wb_pts_, &wb_src_, &wb_starts_, &wb_cand_ids_, &wb_cand_d_, &wb_cand_n_, &wb_status_,
-                      &wb_req_cnt_, &wb_req_node_, &wb_req_dist_, &wb_active_, &wb_nactive_})
+                      &wb_req_key_, &wb_req_dist_, &wb_req_key2_, &wb_req_dist2_, &wb_sort_tmp_, &wb_active_, &wb_nactive_, &wb_extra_ids_, &wb_extra_d_, &wb_extra_n_})
         b->release();
     build_seconds = std::chrono::duration<double>(clk::now() - t0).count();
 }
 
 void Engine::ensure_graph() {
     if (method_ != Method::Hnsw || !graph_dirty_) return;
-    if (use_gpu_build()) {
+    if (use_gpu_build() || (!parent_ && resolve_shards() > 1)) {
         finalize();
         return;
     }
@@ -636,6 +671,16 @@ void Engine::ensure_graph() {
 void Engine::finalize() {
     if (!created_) throw EngineError(Err::IndexBuildFailed, "Index not built");
     if (!dirty_) return;
+    if (!parent_) {
+        const int nsh = resolve_shards();
+        if (nsh > 1) {
+            finalize_sharded(nsh);
+            dirty_ = false;
+            graph_dirty_ = false;
+            return;
+        }
+        shards_.clear();
+    }
     if (method_ == Method::Hnsw && graph_dirty_ && use_gpu_build()) {
         check_device();
         upload_rows();
@@ -648,7 +693,7 @@ void Engine::finalize() {
     check_device();
     upload_rows();
     if (method_ == Method::Brute) {
-        const size_t n = ids_.size();
+        const size_t n = size();
         if (is_u8()) {
             const size_t n_pad = (size_t)bf_u8_rows_padded((int)n);
             d_aux_.ensure(n_pad * 4);
@@ -658,14 +703,182 @@ void Engine::finalize() {
                       "prepare u8 rows");
         } else {
             d_aux_.ensure(std::max<size_t>(n, 1) * 4);
-            hip_check(launch_row_aux_f32(d_rows_.as<float>(), (int)n, ldb_, (int)dim_, space_, d_aux_.as<float>(), stream_),
-                      "row aux");
+            const float* sel_rows = d_rows_.as<float>();
+            centred_ = false;
+            d_rows_sel_.release();
+            if ((space_ == SP_L2 || space_ == SP_COSINE || space_ == SP_ANGULAR) && n > 0) {
+                // L2 is translation invariant, the Q.B^T score q.b - |b|^2/2 is not: its f32 rounding error grows with
+                // |q||b|, i.e. with a common offset of the data, and can exceed the gaps between neighbours (the
+                // reference's direct sum (a-b)^2, distcomp_lp.cc:304-365, has no such term).  When the column mean
+                // is not small against the spread, SELECTION runs on rows - mean and queries - mean; the exact
+                // re-rank keeps using the original rows.  Cosine / angular: same centred copy, and the score is
+                // rebuilt as 1 - cos = (|q'-b'|^2 - (|q|-|b|)^2) / (2|q||b|) (bf_kernels.hip, BF_COSC).
+                std::vector<double> st((size_t)ldb_ + 1);
+                DevBuf d_stats;
+                d_stats.ensure(st.size() * 8);
+                hip_check(launch_col_stats(d_rows_.as<float>(), (int)n, ldb_, (int)dim_, d_stats.as<double>(), stream_),
+                          "column stats");
+                hip_check(hipMemcpyAsync(st.data(), d_stats.ptr(), st.size() * 8, hipMemcpyDeviceToHost, stream_), "stats D2H");
+                hip_check(hipStreamSynchronize(stream_), "column stats");
+                double mu2 = 0;
+                std::vector<float> mean((size_t)ldb_, 0.f);
+                for (size_t c = 0; c < dim_; ++c) {
+                    const double m = st[c] / (double)n;
+                    mean[c] = (float)m;
+                    mu2 += m * m;
+                }
+                const double spread2 = std::max(0.0, st[(size_t)ldb_] / (double)n - mu2);
+                bool centre = mu2 > 0.0625 * spread2;
+                if (const char* env = getenv("NMSLIB_GPU_CENTER")) centre = atoi(env) != 0;
+                if (centre) {
+                    d_mean_.ensure((size_t)ldb_ * 4);
+                    d_rows_sel_.ensure(n * (size_t)ldb_ * 4);
+                    hip_check(hipMemcpyAsync(d_mean_.ptr(), mean.data(), (size_t)ldb_ * 4, hipMemcpyHostToDevice, stream_), "mean");
+                    hip_check(launch_center_rows(d_rows_.as<float>(), d_mean_.as<float>(), (int)n, (int)n, ldb_, (int)dim_,
+                                                 d_rows_sel_.as<float>(), stream_),
+                              "centre rows");
+                    hip_check(hipStreamSynchronize(stream_), "centre rows");  // `mean` is read by the copy above
+                    sel_rows = d_rows_sel_.as<float>();
+                    centred_ = true;
+                    mu_norm_ = 0;
+                    for (size_t c = 0; c < dim_; ++c) mu_norm_ += (double)mean[c] * (double)mean[c];
+                    mu_norm_ = std::sqrt(mu_norm_);
+                }
+            }
+            if (centred_ && space_ != SP_L2) {
+                d_aux_.ensure(std::max<size_t>(n, 1) * 12);
+                hip_check(launch_row_aux_cosc(d_rows_.as<float>(), sel_rows, (int)n, ldb_, (int)dim_, mu_norm_,
+                                              d_aux_.as<float>(), stream_),
+                          "row aux");
+            } else {
+                hip_check(launch_row_aux_f32(sel_rows, (int)n, ldb_, (int)dim_, space_, d_aux_.as<float>(), stream_),
+                          "row aux");
+            }
         }
         hip_check(hipStreamSynchronize(stream_), "finalize");
     } else {
         upload_graph();
     }
     dirty_ = false;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Row shards behind one handle: shard s owns rows [s*n/S, (s+1)*n/S) on device (base + s) % count,
+// with its own workspaces, stream and (HNSW) graph.  A query batch goes to every shard; per-shard top-k lists are
+// copied peer-to-peer to the primary device and merged there by (distance, global position) -- for the exact scan
+// that is bit for bit the unsharded result.  Nothing here needs torch or RCCL: the caller of nmslib_knn_query_batch
+// gets all GPUs of the node.  Shards hold windows of this engine's host rows, not copies.
+// ---------------------------------------------------------------------------------------------
+int Engine::resolve_shards() const {
+    if (loaded_graph_ || parent_ || ids_.empty()) return 1;
+    int want = gpu_shards_;
+    if (want < 0) {
+        if (const char* env = getenv("NMSLIB_GPU_SHARDS")) want = atoi(env);
+        // a process that was given its device (one rank per GPU, bench.py) keeps to it
+        else if (getenv("NMSLIB_GPU_DEVICE") || getenv("LOCAL_RANK")) return 1;
+    }
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
+        (void)hipGetLastError();
+        return 1;  // finalize() reports the missing device
+    }
+    const size_t n = ids_.size();
+    if (want < 0) want = (int)std::min<size_t>((size_t)count, std::max<size_t>(1, n / 1000000));  // auto: 1M rows per shard
+    else if (want == 0) want = count;
+    if ((size_t)want > n) want = (int)n;
+    return std::max(1, want);
+}
+
+void Engine::finalize_sharded(int nshards) {
+    check_device();  // primary device: queries arrive there, results are merged there
+    int count = 1;
+    hip_check(hipGetDeviceCount(&count), "hipGetDeviceCount");
+    const size_t n = ids_.size();
+    shards_.clear();
+    for (int s = 0; s < nshards; ++s) {
+        std::unique_ptr<Engine> c(new Engine(space_name_, method_name_, is_u8() ? 2 : 0, 0));
+        c->parent_ = this;
+        c->view_lo_ = n * (size_t)s / (size_t)nshards;
+        c->view_n_ = n * (size_t)(s + 1) / (size_t)nshards - c->view_lo_;
+        c->dim_ = dim_;
+        c->method_ = method_;
+        c->bp_ = bp_;
+        c->created_ = true;
+        c->forced_device_ = (device_ + s) % count;
+        shards_.push_back(std::move(c));
+    }
+    // build all shards at once: every shard has its own device (or at least its own stream)
+    std::vector<std::string> errors((size_t)nshards);
+    std::vector<std::thread> th;
+    auto t0 = clk::now();
+    for (int s = 0; s < nshards; ++s)
+        th.emplace_back([&, s] {
+            try {
+                shards_[(size_t)s]->finalize();
+            } catch (const std::exception& e) {
+                errors[(size_t)s] = e.what();
+                if (errors[(size_t)s].empty()) errors[(size_t)s] = "failed";
+            }
+        });
+    for (auto& t : th) t.join();
+    for (int s = 0; s < nshards; ++s)
+        if (!errors[(size_t)s].empty()) {
+            shards_.clear();
+            throw EngineError(Err::IndexBuildFailed, "shard " + std::to_string(s) + ": " + errors[(size_t)s]);
+        }
+    build_seconds = std::chrono::duration<double>(clk::now() - t0).count();
+    hip_check(hipSetDevice(device_), "hipSetDevice");
+    d_ids_.ensure(std::max<size_t>(n, 1) * 4);  // position -> external id, applied after the merge
+    hip_check(hipMemcpy(d_ids_.ptr(), ids_.data(), n * 4, hipMemcpyHostToDevice), "upload ids");
+    d_n_ = n;
+    for (hipEvent_t e : shard_events_) (void)hipEventDestroy(e);
+    shard_events_.clear();
+    for (int s = 0; s < nshards; ++s) {
+        hip_check(hipSetDevice(shards_[(size_t)s]->device_), "hipSetDevice");
+        hipEvent_t e;
+        hip_check(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate");
+        shard_events_.push_back(e);
+    }
+    hip_check(hipSetDevice(device_), "hipSetDevice");
+    if (!shard_ready_) hip_check(hipEventCreateWithFlags(&shard_ready_, hipEventDisableTiming), "hipEventCreate");
+}
+
+void Engine::knn_sharded(const void* d_queries, size_t nq, size_t elem_count, size_t k, int32_t* d_ids, float* d_dists,
+                         int32_t* d_cnt, hipStream_t stream) {
+    const size_t S = shards_.size();
+    const size_t qbytes = nq * elem_count * elem_bytes();
+    have_counters_ = false;
+    ws_sh_ids_.ensure(S * nq * k * 4);
+    ws_sh_d_.ensure(S * nq * k * 4);
+    hip_check(hipEventRecord(shard_ready_, stream), "hipEventRecord");  // the queries are ready on the caller's stream
+    for (size_t s = 0; s < S; ++s) {
+        Engine& c = *shards_[s];
+        hip_check(hipSetDevice(c.device_), "hipSetDevice");
+        c.ef_ = ef_;
+        c.algo_ = algo_;
+        hip_check(hipStreamWaitEvent(c.stream_, shard_ready_, 0), "hipStreamWaitEvent");
+        const void* q = d_queries;
+        if (c.device_ != device_) {
+            c.ws_q_.ensure(qbytes);
+            hip_check(hipMemcpyPeerAsync(c.ws_q_.ptr(), c.device_, d_queries, device_, qbytes, c.stream_), "queries P2P");
+            q = c.ws_q_.ptr();
+        }
+        c.ws_ids_.ensure(nq * k * 4);
+        c.ws_dists_.ensure(nq * k * 4);
+        c.knn_device(q, nq, elem_count, k, c.ws_ids_.as<int32_t>(), c.ws_dists_.as<float>(), nullptr, c.stream_);
+        hip_check(hipMemcpyPeerAsync(ws_sh_ids_.as<int32_t>() + s * nq * k, device_, c.ws_ids_.ptr(), c.device_, nq * k * 4,
+                                     c.stream_),
+                  "ids P2P");
+        hip_check(hipMemcpyPeerAsync(ws_sh_d_.as<float>() + s * nq * k, device_, c.ws_dists_.ptr(), c.device_, nq * k * 4,
+                                     c.stream_),
+                  "dists P2P");
+        hip_check(hipEventRecord(shard_events_[s], c.stream_), "hipEventRecord");
+    }
+    hip_check(hipSetDevice(device_), "hipSetDevice");
+    for (size_t s = 0; s < S; ++s) hip_check(hipStreamWaitEvent(stream, shard_events_[s], 0), "hipStreamWaitEvent");
+    hip_check(launch_merge_topk_ex(ws_sh_d_.as<float>(), ws_sh_ids_.as<int32_t>(), nq * k, (int)S, (int)nq, (int)k, d_dists,
+                                   d_ids, d_cnt, d_ids_.as<int32_t>(), stream),
+              "merge_topk");
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -678,6 +891,12 @@ void Engine::knn_device(const void* d_queries, size_t nq, size_t elem_count, siz
     check_device();
     if (nq == 0) return;
     if (k == 0) throw EngineError(Err::InvalidArgument, "k must be positive");
+    if (!shards_.empty()) {
+        if (size() > 0 && elem_count != dim_)
+            throw EngineError(Err::QueryExecutionFailed, "query dimension does not match the index");
+        knn_sharded(d_queries, nq, elem_count, k, d_ids, d_dists, d_cnt, stream);
+        return;
+    }
     if (d_n_ > 0 && elem_count != dim_)
         // SpaceLp::HiddenDistance CHECKs equal lengths (space_lp.cc:27-35) -> the query fails
         throw EngineError(Err::QueryExecutionFailed, "query dimension does not match the index");
@@ -685,8 +904,15 @@ void Engine::knn_device(const void* d_queries, size_t nq, size_t elem_count, siz
     // stay bounded and every slice still fills the chip (the work counters then describe the last slice)
     const size_t slice = method_ == Method::Brute ? 32768 : 65536;
     const size_t qbytes = elem_count * elem_bytes();
+    if (method_ == Method::Hnsw) {  // work counters for the WHOLE batch (slices write at their offset)
+        ws_ndc_.ensure(nq * 4);
+        ws_hops_.ensure(nq * 4);
+        ws_hops_up_.ensure(nq * 4);
+        ws_status_.ensure(nq * 4);
+    }
     for (size_t q0 = 0; q0 < nq; q0 += slice) {
         const size_t m = std::min(slice, nq - q0);
+        ctr_off_ = q0;
         const void* qs = static_cast<const char*>(d_queries) + q0 * qbytes;
         int32_t* cnt = d_cnt ? d_cnt + q0 : nullptr;
         if (method_ == Method::Brute) knn_brute(qs, m, k, d_ids + q0 * k, d_dists + q0 * k, cnt, stream);
@@ -708,6 +934,18 @@ void Engine::knn_brute(const void* d_queries, size_t nq, size_t k, int32_t* d_id
     ws_cand_.ensure(bf_cand_elems(p) * 8);
     ws_cnt_.ensure(bf_cnt_elems(p) * 4);
     hip_check(launch_pad_rows(d_queries, (int)nq, dim_eff, ws_qpad_.ptr(), p.qpad, p.ldb, elem, stream), "pad queries");
+    if (centred_) {
+        ws_qsel_.ensure((size_t)p.qpad * p.ldb * 4);
+        hip_check(launch_center_rows(ws_qpad_.as<float>(), d_mean_.as<float>(), p.qpad, (int)nq, p.ldb, dim_eff,
+                                     ws_qsel_.as<float>(), stream),
+                  "centre queries");
+        if (space_ != SP_L2) {
+            ws_qaux_.ensure((size_t)p.qpad * 16);
+            hip_check(launch_query_aux_cosc(ws_qpad_.as<float>(), ws_qsel_.as<float>(), p.qpad, p.ldb, dim_eff, mu_norm_,
+                                            ws_qaux_.as<float>(), stream),
+                      "query aux");
+        }
+    }
     prof_begin(stream);
     if (is_u8()) {
         hip_check(launch_bf_select_u8(p, d_rows_i8_.as<uint8_t>(), d_aux_.as<int32_t>(), ws_qpad_.as<uint8_t>(),
@@ -718,7 +956,9 @@ void Engine::knn_brute(const void* d_queries, size_t nq, size_t k, int32_t* d_id
                                               ws_cand_.as<unsigned long long>(), ws_cnt_.as<int>(), stream),
                   "bf_select_direct");
     } else {
-        hip_check(launch_bf_select_f32(p, space_, d_rows_.as<float>(), d_aux_.as<float>(), ws_qpad_.as<float>(),
+        hip_check(launch_bf_select_f32(p, space_, centred_ ? d_rows_sel_.as<float>() : d_rows_.as<float>(),
+                                       d_aux_.as<float>(), centred_ ? ws_qsel_.as<float>() : ws_qpad_.as<float>(),
+                                       (centred_ && space_ != SP_L2) ? ws_qaux_.as<float>() : nullptr,
                                        ws_cand_.as<unsigned long long>(), ws_cnt_.as<int>(), stream),
                   "bf_select_f32");
     }
@@ -732,49 +972,111 @@ void Engine::knn_brute(const void* d_queries, size_t nq, size_t k, int32_t* d_id
 void Engine::knn_hnsw(const void* d_queries, size_t nq, size_t k, int32_t* d_ids, float* d_dists, int32_t* d_cnt,
                       hipStream_t stream) {
     const int ef = ef_;
+    // Hnsw::Search, hnsw.cc:724: algoType=old, or hybrid with ef >= 1000, runs SearchOld
+    if (algo_ == "old" || (algo_ == "hybrid" && ef >= 1000)) {
+        knn_hnsw_old(d_queries, nq, k, d_ids, d_dists, d_cnt, stream);
+        return;
+    }
     if (std::max<size_t>(ef, k) > 1024)
-        throw EngineError(Err::QueryTooLarge, "max(ef, k) larger than 1024 is not supported by the HNSW GPU kernel");
-    ws_ndc_.ensure(nq * 4);
-    ws_hops_.ensure(nq * 4);
-    ws_hops_up_.ensure(nq * 4);
-    ws_status_.ensure(nq * 4);
-    DevBuf tmp_cnt;
+        throw EngineError(Err::QueryTooLarge,
+                          "SearchV1Merge with max(ef, k) > 1024 is not supported by the GPU kernel "
+                          "(algoType=old / hybrid with ef >= 1000 has no limit)");
     int32_t* cnt = d_cnt;
     if (!cnt) {
         ws_outcnt_.ensure(nq * 4);
         cnt = ws_outcnt_.as<int32_t>();
     }
+    int32_t* ndc = ws_ndc_.as<int32_t>() + ctr_off_;
+    int32_t* hops = ws_hops_.as<int32_t>() + ctr_off_;
+    int32_t* hops_up = ws_hops_up_.as<int32_t>() + ctr_off_;
+    int32_t* status = ws_status_.as<int32_t>() + ctr_off_;
     HnswSearchPlan p = hnsw_make_plan(dg_, (int)nq, (int)k, ef, false);
-    uint32_t* bitset = nullptr;
+    have_counters_ = true;
     if (p.table_size == 0) {
         ws_bitset_.ensure(nq * p.bitset_words * 4);
         hip_check(hipMemsetAsync(ws_bitset_.ptr(), 0, nq * p.bitset_words * 4, stream), "clear visited bitset");
-        bitset = ws_bitset_.as<uint32_t>();
+        prof_begin(stream);
+        hip_check(launch_hnsw_search(dg_, p, d_queries, ws_bitset_.as<uint32_t>(), d_ids, d_dists, cnt, ndc, hops, hops_up,
+                                     status, stream),
+                  "hnsw_search");
+        prof_end(stream);
+        return;
     }
+    // The LDS visited table is exact but finite.  Queries that fill it append themselves to a list on the device and
+    // are re-run by a second, small launch of the bitset variant that walks that list -- the host never looks at it,
+    // so the call only enqueues work (include/nmslib_gpu.h).
+    const int fix_slots = (int)std::min<size_t>(nq, 128);
+    HnswSearchPlan pb = hnsw_make_plan(dg_, (int)nq, (int)k, ef, true);
+    ws_fix_.ensure((nq + 16) * 4);
+    ws_bitset_.ensure((size_t)fix_slots * pb.bitset_words * 4);
+    int32_t* fix_count = ws_fix_.as<int32_t>();
+    int32_t* fix_list = fix_count + 16;
+    hip_check(hipMemsetAsync(fix_count, 0, 4, stream), "clear overflow count");
     prof_begin(stream);
-    hip_check(launch_hnsw_search(dg_, p, d_queries, bitset, d_ids, d_dists, cnt, ws_ndc_.as<int32_t>(),
-                                 ws_hops_.as<int32_t>(), ws_hops_up_.as<int32_t>(), ws_status_.as<int32_t>(), stream),
+    hip_check(launch_hnsw_search_fix(dg_, p, d_queries, nullptr, 0, fix_list, fix_count, d_ids, d_dists, cnt, ndc, hops,
+                                     hops_up, status, stream),
               "hnsw_search");
     prof_end(stream);
-    have_counters_ = true;
-    if (p.table_size != 0) {
-        // the LDS visited table is exact but finite: queries that filled it report status 1
-        // and are re-run with the HBM bitset variant (rare; costs one host sync)
-        std::vector<int32_t> status(nq);
-        hip_check(hipMemcpyAsync(status.data(), ws_status_.ptr(), nq * 4, hipMemcpyDeviceToHost, stream), "status");
-        hip_check(hipStreamSynchronize(stream), "hnsw_search");
-        bool any = false;
-        for (int32_t s : status) any |= (s != 0);
-        if (any) {
-            HnswSearchPlan pb = hnsw_make_plan(dg_, (int)nq, (int)k, ef, true);
-            ws_bitset_.ensure(nq * pb.bitset_words * 4);
-            hip_check(hipMemsetAsync(ws_bitset_.ptr(), 0, nq * pb.bitset_words * 4, stream), "clear visited bitset");
-            hip_check(launch_hnsw_search(dg_, pb, d_queries, ws_bitset_.as<uint32_t>(), d_ids, d_dists, cnt,
-                                         ws_ndc_.as<int32_t>(), ws_hops_.as<int32_t>(), ws_hops_up_.as<int32_t>(),
-                                         ws_status_.as<int32_t>(), stream),
-                      "hnsw_search(bitset)");
-        }
+    hip_check(launch_hnsw_search_fix(dg_, pb, d_queries, ws_bitset_.as<uint32_t>(), fix_slots, fix_list, fix_count, d_ids,
+                                     d_dists, cnt, ndc, hops, hops_up, status, stream),
+              "hnsw_search(bitset)");
+}
+
+// Hnsw::SearchOld (hnsw_distfunc_opt.cc:46-150) on the GPU: no limit on ef or k.  Queues that outgrow LDS live in
+// per-query HBM workspaces, so very large batches go through in slices of bounded workspace.
+void Engine::knn_hnsw_old(const void* d_queries, size_t nq, size_t k, int32_t* d_ids, float* d_dists, int32_t* d_cnt,
+                          hipStream_t stream) {
+    const int ef = ef_;
+    int32_t* cnt = d_cnt;
+    if (!cnt) {
+        ws_outcnt_.ensure(nq * 4);
+        cnt = ws_outcnt_.as<int32_t>();
     }
+    const size_t qbytes = dim_ * elem_bytes();
+    const size_t co = ctr_off_;
+    bool force_bitset = false;
+    int heap_cap = 0;
+    std::vector<int32_t> status(nq);
+    for (int attempt = 0; attempt < 3; ++attempt) {
+        HnswSearchPlan p0 = hnsw_make_plan_old(dg_, 1, (int)k, ef, force_bitset, heap_cap);
+        const size_t per_q = hnsw_old_ws_a(p0) + hnsw_old_ws_r(p0) + hnsw_old_ws_heap(p0) + p0.bitset_words * 4;
+        const size_t budget = (size_t)4 << 30;
+        const size_t slice = std::max<size_t>(1, std::min<size_t>(nq, per_q ? budget / per_q : nq));
+        for (size_t q0 = 0; q0 < nq; q0 += slice) {
+            const size_t m = std::min(slice, nq - q0);
+            HnswSearchPlan p = hnsw_make_plan_old(dg_, (int)m, (int)k, ef, force_bitset, heap_cap);
+            uint32_t* bitset = nullptr;
+            if (p.table_size == 0) {
+                ws_bitset_.ensure(m * p.bitset_words * 4);
+                hip_check(hipMemsetAsync(ws_bitset_.ptr(), 0, m * p.bitset_words * 4, stream), "clear visited bitset");
+                bitset = ws_bitset_.as<uint32_t>();
+            }
+            ws_old_a_.ensure(std::max<size_t>(16, m * hnsw_old_ws_a(p)));
+            ws_old_r_.ensure(std::max<size_t>(16, m * hnsw_old_ws_r(p)));
+            ws_old_heap_.ensure(std::max<size_t>(16, m * hnsw_old_ws_heap(p)));
+            if (q0 == 0 && attempt == 0) prof_begin(stream);
+            hip_check(launch_hnsw_search_old(dg_, p, static_cast<const char*>(d_queries) + q0 * qbytes, bitset,
+                                             ws_old_a_.ptr(), ws_old_r_.ptr(), ws_old_heap_.ptr(), d_ids + q0 * k,
+                                             d_dists + q0 * k, cnt + q0, ws_ndc_.as<int32_t>() + co + q0,
+                                             ws_hops_.as<int32_t>() + co + q0, ws_hops_up_.as<int32_t>() + co + q0,
+                                             ws_status_.as<int32_t>() + co + q0, stream),
+                      "hnsw_search_old");
+            if (q0 == 0 && attempt == 0) prof_end(stream);
+        }
+        have_counters_ = true;
+        // status 1: the LDS visited table filled up -> HBM bitsets; status 2: the candidate heap outgrew its bound
+        hip_check(hipMemcpyAsync(status.data(), ws_status_.as<int32_t>() + co, nq * 4, hipMemcpyDeviceToHost, stream), "status");
+        hip_check(hipStreamSynchronize(stream), "hnsw_search_old");
+        bool any1 = false, any2 = false;
+        for (int32_t v : status) {
+            any1 |= v == 1;
+            any2 |= v == 2;
+        }
+        if (!any1 && !any2) return;
+        if (any1) force_bitset = true;
+        if (any2) heap_cap = (int)std::min<size_t>(d_n_ + 1, (size_t)INT32_MAX);
+    }
+    throw EngineError(Err::QueryExecutionFailed, "SearchOld: queue workspaces exhausted");
 }
 
 void Engine::knn_host(const void* queries, size_t nq, size_t elem_count, size_t k, std::vector<int32_t>& ids,
@@ -807,6 +1109,17 @@ size_t Engine::range_host(const void* query, size_t elem_count, double radius, s
     const size_t n = d_n_;
     if (n == 0 || capacity == 0) return 0;
     if (elem_count != dim_) throw EngineError(Err::QueryExecutionFailed, "query dimension does not match the index");
+    if (!shards_.empty()) {
+        // insertion order = shard order; shards report global positions
+        size_t got = 0;
+        for (auto& c : shards_) {
+            if (got >= capacity) break;
+            got += c->range_host(query, elem_count, radius, capacity - got, ids + got, dists + got);
+        }
+        for (size_t i = 0; i < got; ++i) ids[i] = ids_[(size_t)ids[i]];
+        hip_check(hipSetDevice(device_), "hipSetDevice");
+        return got;
+    }
     // RangeQuery<dist_t>(space, obj, static_cast<dist_t>(radius)), nmslib_c.cpp:1092-1093
     const float r = is_u8() ? (float)(int)radius : (float)radius;
     const int ld = is_u8() ? 128 : ldb_;
@@ -870,6 +1183,9 @@ static void rd(std::istream& i, T& v) {
 
 void Engine::save(const std::string& path, bool save_data) {
     if (!created_) throw EngineError(Err::InvalidArgument, "Index not built");
+    if (method_ == Method::Hnsw && !loaded_graph_ && resolve_shards() > 1)
+        throw EngineError(Err::DataIO, "a sharded HNSW index holds one graph per GPU and has no single-file form; "
+                                       "build with gpu_shards=1 to save it in the reference's format");
     ensure_graph();  // persistence is host-side: no device needed
     const size_t n = ids_.size();
     if (save_data) {

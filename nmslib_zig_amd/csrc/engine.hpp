@@ -98,7 +98,9 @@ struct HnswBuildParams {
     bool skip_optimized = false;
     int gpu_build = -1;       // engine extension: 1 = batched construction on the GPU, 0 = host, -1 = auto
     int gpu_build_batch = 0;  // max nodes inserted per batch (0 = default)
+    int gpu_build_div = 0;    // a batch is at most 1/div of the graph built so far (0 = default)
 };
+
 
 void hnsw_check_params(const HnswBuildParams& bp);
 std::vector<int32_t> hnsw_random_levels(size_t n, const HnswBuildParams& bp);
@@ -121,7 +123,7 @@ class Engine {
     const std::string& space_name() const { return space_name_; }
     const std::string& method_name() const { return method_name_; }
     bool is_u8() const { return space_ == SP_L2SQR_SIFT; }
-    size_t size() const { return ids_.size(); }
+    size_t size() const { return parent_ ? view_n_ : ids_.size(); }
     size_t dim() const { return dim_; }
     size_t elem_bytes() const { return is_u8() ? 1 : 4; }
     size_t row_bytes() const { return dim_ * elem_bytes(); }
@@ -168,7 +170,25 @@ class Engine {
 
     std::mutex mu;  // serialises finalize + queries on one index
 
+    // ---- row shards behind one handle (index parameter gpu_shards) ----
+    size_t shard_count() const { return shards_.size(); }
+
    private:
+    // host rows / ids of this engine: its own, or (shard child) a window of the parent's
+    const float* rows_f32() const { return parent_ ? parent_->rows_f32_.data() + view_lo_ * dim_ : rows_f32_.data(); }
+    const uint8_t* rows_u8() const { return parent_ ? parent_->rows_u8_.data() + view_lo_ * 128 : rows_u8_.data(); }
+    int resolve_shards() const;
+    void finalize_sharded(int nshards);
+    void knn_sharded(const void* d_queries, size_t nq, size_t elem_count, size_t k, int32_t* d_ids, float* d_dists,
+                     int32_t* d_cnt, hipStream_t stream);
+    std::vector<std::unique_ptr<Engine>> shards_;
+    std::vector<hipEvent_t> shard_events_;
+    hipEvent_t shard_ready_ = nullptr;
+    const Engine* parent_ = nullptr;  // shard child: rows [view_lo_, view_lo_ + view_n_) of the parent, no copy
+    size_t view_lo_ = 0, view_n_ = 0;
+    int forced_device_ = -1;
+    int gpu_shards_ = -1;  // index parameter: -1 unset, 0 = all visible devices, N = that many
+    DevBuf ws_sh_ids_, ws_sh_d_;
     void check_device();
     void ensure_graph();
     void upload_rows();
@@ -181,6 +201,8 @@ class Engine {
                    int32_t* d_cnt, hipStream_t stream);
     void knn_hnsw(const void* d_queries, size_t nq, size_t k, int32_t* d_ids, float* d_dists,
                   int32_t* d_cnt, hipStream_t stream);
+    void knn_hnsw_old(const void* d_queries, size_t nq, size_t k, int32_t* d_ids, float* d_dists,
+                      int32_t* d_cnt, hipStream_t stream);
 
     std::string space_name_, method_name_;
     int space_ = SP_L2;
@@ -205,15 +227,20 @@ class Engine {
     int device_ = -1;
     hipStream_t stream_ = nullptr;
     DevBuf d_rows_, d_rows_i8_, d_aux_, d_ids_, d_links0_, d_up_off_, d_up_links_, d_rownorm_;
+    DevBuf d_rows_sel_, d_mean_;  // brute-force L2 on un-centred data: selection copy (rows - column mean) and the mean
+    bool centred_ = false;
+    double mu_norm_ = 0;  // |column mean| (centred cosine scoring)
     size_t d_n_ = 0;
     int ldb_ = 0;
     HnswDeviceGraph dg_{};
 
     // workspaces
-    DevBuf ws_q_, ws_qpad_, ws_cand_, ws_cnt_, ws_ids_, ws_dists_, ws_outcnt_, ws_status_, ws_bitset_;
-    DevBuf ws_ndc_, ws_hops_, ws_hops_up_, ws_pair_, ws_rdist_, ws_rcnt_;
-    DevBuf wb_pts_, wb_src_, wb_starts_, wb_cand_ids_, wb_cand_d_, wb_cand_n_, wb_status_, wb_req_cnt_, wb_req_node_,
-        wb_req_dist_, wb_active_, wb_nactive_;  // construction workspaces (released after the build)
+    DevBuf ws_q_, ws_qpad_, ws_qsel_, ws_qaux_, ws_cand_, ws_cnt_, ws_ids_, ws_dists_, ws_outcnt_, ws_status_, ws_bitset_;
+    DevBuf ws_ndc_, ws_hops_, ws_hops_up_, ws_pair_, ws_rdist_, ws_rcnt_, ws_old_a_, ws_old_r_, ws_old_heap_;
+    DevBuf wb_pts_, wb_src_, wb_starts_, wb_cand_ids_, wb_cand_d_, wb_cand_n_, wb_status_, wb_req_key_, wb_req_dist_,
+        wb_req_key2_, wb_req_dist2_, wb_sort_tmp_, wb_active_, wb_nactive_, wb_extra_ids_, wb_extra_d_, wb_extra_n_;  // construction workspaces (released after the build)
+    DevBuf ws_fix_;       // visited-overflow list of the HNSW search (count + query ids), device only
+    size_t ctr_off_ = 0;  // offset of the current slice inside the per-batch counter arrays
     bool have_counters_ = false;
     bool prof_ = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events_;

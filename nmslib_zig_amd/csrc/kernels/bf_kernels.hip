@@ -26,11 +26,13 @@
 
 namespace gfxknn {
 
-enum BfMode : int { BF_L2 = 0, BF_DOT = 1, BF_COS = 2, BF_L1 = 3, BF_LINF = 4 };
+enum BfMode : int { BF_L2 = 0, BF_DOT = 1, BF_COS = 2, BF_L1 = 3, BF_LINF = 4, BF_COSC = 5 };
 
 struct BfArgs {
     const float* base;
     const float* aux;
+    const float* qaux;  // BF_COSC: [qpad][4] = |q'|^2, |q| - |mu|, |q|, 1 (0 for a zero-norm query)
+    int aux_stride;     // BF_COSC: aux holds three planes of this many floats (-|b'|^2, |b| - |mu|, 1/|b|)
     const float* queries;
     u64* cand;
     int* cand_cnt;
@@ -234,13 +236,19 @@ __global__ __launch_bounds__(256, 2) void bf_select_f32_kernel(BfArgs a) {
 
     constexpr bool kDirect = (MODE == BF_L1 || MODE == BF_LINF);
     constexpr bool kDelay = !kDirect;  // epilogue of stage s overlapped with the MFMAs of s+1
-    constexpr bool kAux = (MODE == BF_L2 || MODE == BF_COS);
+    // BF_COSC = cosine / angular on data with a large common offset: the tile holds CENTRED rows b' = b - mu and the
+    // score is -(1 - cos)|q| rebuilt from small quantities only,
+    //     1 - cos(q,b) = (|q'-b'|^2 - (|q|-|b|)^2) / (2|q||b|),    |q'-b'|^2 = |q'|^2 + |b'|^2 - 2 q'.b',
+    // so the f32 rounding of the MFMA dot product is relative to |q'||b'| (the spread), not to |q||b| (the offset).
+    constexpr bool kCosC = (MODE == BF_COSC);
+    constexpr int kAuxN = kCosC ? 3 : 1;
+    constexpr bool kAux = (MODE == BF_L2 || MODE == BF_COS || kCosC);
 
     const int kcs = FULL ? BF_KC : a.kcs;
     const int lds_stride = kcs + 4;  // +16 B pad: conflict-free ds_read_b128 of 32 rows
     float* tile = reinterpret_cast<float*>(smem);                      // [2][BN][lds_stride]
-    float* auxs = tile + 2 * BF_BN * lds_stride;                       // [4][BN], 3 in rotation
-    u64* scratch = reinterpret_cast<u64*>(auxs + 4 * BF_BN) + (size_t)wave * a.cap;  // [4][cap]
+    float* auxs = tile + 2 * BF_BN * lds_stride;                       // [4][kAuxN][BN], 3 in rotation
+    u64* scratch = reinterpret_cast<u64*>(auxs + 4 * BF_BN * 3) + (size_t)wave * a.cap;  // [4][cap]
 
     const int qidx = qt * BF_TQ + wave * 32 + l31;  // this lane's query (row of the padded batch)
     const int half = a.cap >> 1;
@@ -269,7 +277,8 @@ __global__ __launch_bounds__(256, 2) void bf_select_f32_kernel(BfArgs a) {
     // staging map: 32 threads per row (16 B each), 8 rows per pass, 8 passes = 64 rows
     const int sc = tid & 31, sr = tid >> 5;
     f32x4 stg[8];
-    float stg_aux = 0.f;
+    float stg_aux[kAuxN];
+    float cq2 = 0.f, cqnp = 0.f, cqn = 0.f, cqf = 1.f;  // BF_COSC: this lane's query constants
 
     auto issue_loads = [&](int step) __attribute__((always_inline)) {
         const int stage = step / nchunks, kc = step - stage * nchunks;
@@ -288,7 +297,11 @@ __global__ __launch_bounds__(256, 2) void bf_select_f32_kernel(BfArgs a) {
             // rows past the end of the split get -inf: L2 score = dot + (-inf), cosine score =
             // 0 * (-inf) = NaN -- neither can pass "s > thr", so those modes need no position test
             const int row = row0 + tid;
-            stg_aux = row < r_end ? a.aux[row] : -INFINITY;
+            stg_aux[0] = row < r_end ? a.aux[row] : -INFINITY;
+            if constexpr (kCosC) {
+                stg_aux[1] = row < r_end ? a.aux[(size_t)a.aux_stride + row] : 0.f;
+                stg_aux[2] = row < r_end ? a.aux[2 * (size_t)a.aux_stride + row] : 1.f;
+            }
         }
     };
     auto write_lds = [&](int step) __attribute__((always_inline)) {
@@ -301,7 +314,10 @@ __global__ __launch_bounds__(256, 2) void bf_select_f32_kernel(BfArgs a) {
         }
         // aux rotates over three buffers: the delayed epilogue of stage s still reads buffer
         // s % 3 while stage s+2's values are being written
-        if (kAux && kc == 0 && tid < BF_BN) auxs[(stage % 3) * BF_BN + tid] = stg_aux;
+        if (kAux && kc == 0 && tid < BF_BN) {
+#pragma unroll
+            for (int c = 0; c < kAuxN; ++c) auxs[((stage % 3) * kAuxN + c) * BF_BN + tid] = stg_aux[c];
+        }
     };
 
     // one eighth of write_lds (rows sr + 8*i): issued between MFMA groups so that the staging of the
@@ -312,7 +328,10 @@ __global__ __launch_bounds__(256, 2) void bf_select_f32_kernel(BfArgs a) {
     };
     auto write_lds_aux = [&](int step) __attribute__((always_inline)) {
         const int stage = step / nchunks, kc = step - stage * nchunks;
-        if (kAux && kc == 0 && tid < BF_BN) auxs[(stage % 3) * BF_BN + tid] = stg_aux;
+        if (kAux && kc == 0 && tid < BF_BN) {
+#pragma unroll
+            for (int c = 0; c < kAuxN; ++c) auxs[((stage % 3) * kAuxN + c) * BF_BN + tid] = stg_aux[c];
+        }
     };
     // query fragments: lane (l31, h) holds dims 8t + 4h + {0..3} of its query, t = 0..15
     f32x4 bq[16];
@@ -360,7 +379,12 @@ __global__ __launch_bounds__(256, 2) void bf_select_f32_kernel(BfArgs a) {
     auto score_of = [&](float acc, int row, const float* ax) __attribute__((always_inline)) -> float {
         if constexpr (kDirect) return -acc;  // smaller distance = better score
         else if constexpr (MODE == BF_COS) return acc * ax[row];
-        else return acc;
+        else if constexpr (kCosC) {
+            const float t = cqnp - ax[BF_BN + row];
+            const float inv = ax[2 * BF_BN + row];
+            const float v = fmaf(t, t, fmaf(2.f, acc, ax[row] - cq2)) * (0.5f * inv);
+            return cqf * (inv == 0.f ? -cqn : v);  // zero-norm row: similarity 0 (distcomp_scalar.cc:83-168)
+        } else return acc;
     };
     auto consider = [&](float s, int pos, bool lastst) __attribute__((always_inline)) {
         bool pass = s > thr;
@@ -420,7 +444,7 @@ __global__ __launch_bounds__(256, 2) void bf_select_f32_kernel(BfArgs a) {
     // The 16 scores of one finished 32-row block.  Fast path: one max over the block and one
     // compare; the element-wise path runs only when some lane of the wave has a hit.
     auto check_block = [&](const f32x16& o, int blk, int stage) __attribute__((always_inline)) {
-        const float* ax = auxs + (stage % 3) * BF_BN;
+        const float* ax = auxs + (stage % 3) * kAuxN * BF_BN;
         const int row0 = r_begin + stage * BF_BN + blk * 32;
         const bool lastst = stage == nstages - 1;
         float sc[16];
@@ -559,6 +583,13 @@ __global__ __launch_bounds__(256, 2) void bf_select_f32_kernel(BfArgs a) {
     if (nsteps > 0) {
         issue_loads(0);
         write_lds(0);
+    }
+    if constexpr (kCosC) {
+        const f32x4 qa = *reinterpret_cast<const f32x4*>(a.qaux + (size_t)qidx * 4);
+        cq2 = qa[0];
+        cqnp = qa[1];
+        cqn = qa[2];
+        cqf = qa[3];
     }
     if (nchunks == 1) {
         load_queries(0);
@@ -1045,6 +1076,95 @@ __global__ void normalize_rows_kernel(float* rows, int n, int ld, int dim) {
     }
 }
 
+// Column sums of the stored rows (f64 accumulators): stats[c] = sum_r base[r][c], stats[ldb] = sum of squares of everything.
+// One-off at finalize: decides whether the L2 selection runs on a centred copy (see launch_center_rows).
+__global__ void col_stats_kernel(const float* base, int n, int ldb, int dim, int rows_per_block, double* stats) {
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int r0 = blockIdx.x * rows_per_block;
+    const int r1 = min(n, r0 + rows_per_block);
+    double sq = 0.0;
+    for (int c = tx; c < dim; c += 64) {
+        double s = 0.0;
+        for (int r = r0 + ty; r < r1; r += 4) {
+            const double v = (double)base[(size_t)r * ldb + c];
+            s += v;
+            sq += v * v;
+        }
+        atomicAdd(&stats[c], s);
+    }
+    atomicAdd(&stats[ldb], sq);
+}
+
+// dst[r][c] = src[r][c] - mean[c] for c < dim (pad columns stay 0); rows >= rows_valid are copied unchanged
+__global__ void center_rows_kernel(const float* src, const float* mean, int rows, int rows_valid, int ld, int dim, float* dst) {
+    const size_t total = (size_t)rows * ld;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = i / ld;
+        const int c = (int)(i - r * ld);
+        const float v = src[i];
+        dst[i] = (c < dim && r < (size_t)rows_valid) ? v - mean[c] : v;
+    }
+}
+
+// BF_COSC preparation.  Rows: aux[0][r] = -|b'|^2, aux[1][r] = |b| - |mu|, aux[2][r] = 1/|b| (0 for a zero-norm row: the
+// reference's rule norm^2 < 2*FLT_MIN -> similarity 0).  Norms are accumulated in f64: |b| - |mu| is a small
+// difference of large numbers.
+__global__ void row_aux_cosc_kernel(const float* orig, const float* centred, int n, int ldb, int dim, double mu_norm,
+                                    float* aux) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= n) return;
+    const float* p = orig + (size_t)row * ldb;
+    const float* c = centred + (size_t)row * ldb;
+    double nb2 = 0.0;
+    float a = 0.f, nf = 0.f;
+    for (int d = lane; d < dim; d += 64) {
+        const float x = p[d], y = c[d];
+        nb2 += (double)x * (double)x;
+        nf = fmaf(x, x, nf);
+        a = fmaf(y, y, a);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) nb2 += __shfl_xor(nb2, o, 64);
+    a = wave_sum(a);
+    nf = wave_sum(nf);
+    if (lane == 0) {
+        const double nb = sqrt(nb2);
+        aux[row] = -a;
+        aux[(size_t)n + row] = (float)(nb - mu_norm);
+        aux[2 * (size_t)n + row] = (nf < 1.17549435e-38f * 2.0f) ? 0.f : (float)(1.0 / nb);
+    }
+}
+// Queries: qaux[q] = {|q'|^2, |q| - |mu|, |q|, 1 or 0 (zero-norm query: every distance is 1, positions decide)}
+__global__ void query_aux_cosc_kernel(const float* orig, const float* centred, int nq, int ldb, int dim, double mu_norm,
+                                      float* qaux) {
+    const int lane = threadIdx.x & 63;
+    const int q = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (q >= nq) return;
+    const float* p = orig + (size_t)q * ldb;
+    const float* c = centred + (size_t)q * ldb;
+    double n2 = 0.0;
+    float a = 0.f, nf = 0.f;
+    for (int d = lane; d < dim; d += 64) {
+        const float x = p[d], y = c[d];
+        n2 += (double)x * (double)x;
+        nf = fmaf(x, x, nf);
+        a = fmaf(y, y, a);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) n2 += __shfl_xor(n2, o, 64);
+    a = wave_sum(a);
+    nf = wave_sum(nf);
+    if (lane == 0) {
+        const double nn = sqrt(n2);
+        const bool zero = nf < 1.17549435e-38f * 2.0f;
+        qaux[(size_t)q * 4 + 0] = a;
+        qaux[(size_t)q * 4 + 1] = (float)(nn - mu_norm);
+        qaux[(size_t)q * 4 + 2] = (float)nn;
+        qaux[(size_t)q * 4 + 3] = zero ? 0.f : 1.f;
+    }
+}
+
 __global__ void pair_distance_kernel(int space, const void* a, const void* b, int dim, float* out) {
     const int lane = threadIdx.x & 63;
     float d;
@@ -1057,7 +1177,8 @@ __global__ void pair_distance_kernel(int space, const void* a, const void* b, in
 
 // per-shard top-k lists -> global top-k by (distance, id); one wave per query
 __global__ void merge_topk_kernel(const float* dists_in, const int32_t* ids_in, size_t shard_stride, int nshards,
-                                  int nq, int k, float* dists_out, int32_t* ids_out) {
+                                  int nq, int k, float* dists_out, int32_t* ids_out, int32_t* cnt_out,
+                                  const int32_t* ext_ids) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     u64* keys = reinterpret_cast<u64*>(smem);
     const int q = blockIdx.x, tid = threadIdx.x;
@@ -1078,8 +1199,14 @@ __global__ void merge_topk_kernel(const float* dists_in, const int32_t* ids_in, 
     for (int i = tid; i < k; i += blockDim.x) {
         const u64 key = keys[i];
         const bool ok = key != ~0ull;
-        ids_out[(size_t)q * k + i] = ok ? (int32_t)(uint32_t)key : -1;
+        const int32_t id = (int32_t)(uint32_t)key;
+        ids_out[(size_t)q * k + i] = ok ? (ext_ids ? ext_ids[id] : id) : -1;
         dists_out[(size_t)q * k + i] = ok ? ord_f32((uint32_t)(key >> 32)) : INFINITY;
+    }
+    if (cnt_out && tid == 0) {
+        int c = 0;
+        while (c < k && keys[c] != ~0ull) ++c;
+        cnt_out[q] = c;
     }
 }
 
@@ -1137,7 +1264,7 @@ BfPlan bf_make_plan(int n, int dim, int nq, int k, bool is_u8) {
     if (is_u8)
         p.lds_select = 6 * BF_BN * 128 + 8 * BF_BN * 4 + 4 * (size_t)p.cap * 8;  // DMA ring + aux ring + scratch
     else
-        p.lds_select = (size_t)2 * BF_BN * (kcs + 4) * 4 + 2 * BF_BN * 4 + BF_TQ * 4 + 4 * (size_t)p.cap * 8;
+        p.lds_select = (size_t)2 * BF_BN * (kcs + 4) * 4 + 4 * BF_BN * 3 * 4 + 4 * (size_t)p.cap * 8;  // tiles + aux planes + scratch
     p.lds_rerank = (size_t)p.p2max * 8 + (p.nsplit + 1) * 4 + 16;
     return p;
 }
@@ -1218,8 +1345,8 @@ static BfArgs make_args(const BfPlan& p, const float* base, const float* aux, co
 }
 
 hipError_t launch_bf_select_f32(const BfPlan& p, int space, const float* base, const float* aux,
-                                const float* queries_padded, unsigned long long* cand, int* cand_cnt,
-                                hipStream_t s) {
+                                const float* queries_padded, const float* qaux_cosc, unsigned long long* cand,
+                                int* cand_cnt, hipStream_t s) {
     // per-query shared thresholds live behind the survivor counts; cleared for every batch
     uint32_t* gthr = reinterpret_cast<uint32_t*>(cand_cnt + (size_t)p.qpad * p.nsplit);
     hipError_t me = hipMemsetAsync(gthr, 0, ((size_t)p.qpad + (size_t)p.qpad * p.nsplit) * 4, s);
@@ -1229,7 +1356,13 @@ hipError_t launch_bf_select_f32(const BfPlan& p, int space, const float* base, c
         case SP_L2: return launch_select_mode<BF_L2>(p, a, s);
         case SP_NEGDOT: return launch_select_mode<BF_DOT>(p, a, s);
         case SP_COSINE:
-        case SP_ANGULAR: return launch_select_mode<BF_COS>(p, a, s);
+        case SP_ANGULAR:
+            if (qaux_cosc) {  // centred rows + three aux planes (engine: centred_)
+                a.qaux = qaux_cosc;
+                a.aux_stride = p.n;
+                return launch_select_mode<BF_COSC>(p, a, s);
+            }
+            return launch_select_mode<BF_COS>(p, a, s);
         default: return hipErrorInvalidValue;
     }
 }
@@ -1331,6 +1464,37 @@ hipError_t launch_normalize_rows(float* rows, int n, int ld, int dim, hipStream_
     hipLaunchKernelGGL(normalize_rows_kernel, dim3((n + 3) / 4), dim3(256), 0, s, rows, n, ld, dim);
     return hipGetLastError();
 }
+hipError_t launch_row_aux_cosc(const float* orig, const float* centred, int n, int ldb, int dim, double mu_norm, float* aux,
+                               hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(row_aux_cosc_kernel, dim3((n + 3) / 4), dim3(256), 0, s, orig, centred, n, ldb, dim, mu_norm, aux);
+    return hipGetLastError();
+}
+hipError_t launch_query_aux_cosc(const float* orig, const float* centred, int nq, int ldb, int dim, double mu_norm,
+                                 float* qaux, hipStream_t s) {
+    if (nq == 0) return hipSuccess;
+    hipLaunchKernelGGL(query_aux_cosc_kernel, dim3((nq + 3) / 4), dim3(256), 0, s, orig, centred, nq, ldb, dim, mu_norm,
+                       qaux);
+    return hipGetLastError();
+}
+hipError_t launch_col_stats(const float* base, int n, int ldb, int dim, double* stats, hipStream_t s) {
+    hipError_t e = hipMemsetAsync(stats, 0, ((size_t)ldb + 1) * 8, s);
+    if (e != hipSuccess || n == 0) return e;
+    int grid = (n + 255) / 256;
+    if (grid > 2048) grid = 2048;
+    const int rpb = (n + grid - 1) / grid;
+    hipLaunchKernelGGL(col_stats_kernel, dim3(grid), dim3(256), 0, s, base, n, ldb, dim, rpb, stats);
+    return hipGetLastError();
+}
+hipError_t launch_center_rows(const float* src, const float* mean, int rows, int rows_valid, int ld, int dim, float* dst,
+                              hipStream_t s) {
+    const size_t total = (size_t)rows * ld;
+    if (total == 0) return hipSuccess;
+    size_t grid = (total + 255) / 256;
+    if (grid > 8192) grid = 8192;
+    hipLaunchKernelGGL(center_rows_kernel, dim3((unsigned)grid), dim3(256), 0, s, src, mean, rows, rows_valid, ld, dim, dst);
+    return hipGetLastError();
+}
 hipError_t launch_pair_distance(int space, const void* a, const void* b, int dim, float* out,
                                 hipStream_t s) {
     hipLaunchKernelGGL(pair_distance_kernel, dim3(1), dim3(64), 0, s, space, a, b, dim, out);
@@ -1338,13 +1502,18 @@ hipError_t launch_pair_distance(int space, const void* a, const void* b, int dim
 }
 hipError_t launch_merge_topk(const float* dists_in, const int32_t* ids_in, size_t shard_stride, int nshards, int nq,
                              int k, float* dists_out, int32_t* ids_out, hipStream_t s) {
+    return launch_merge_topk_ex(dists_in, ids_in, shard_stride, nshards, nq, k, dists_out, ids_out, nullptr, nullptr, s);
+}
+hipError_t launch_merge_topk_ex(const float* dists_in, const int32_t* ids_in, size_t shard_stride, int nshards, int nq,
+                                int k, float* dists_out, int32_t* ids_out, int32_t* cnt_out, const int32_t* ext_ids,
+                                hipStream_t s) {
     const int P = host_next_pow2(nshards * k < 2 ? 2 : nshards * k);
     const size_t lds = (size_t)P * 8;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(merge_topk_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(merge_topk_kernel, dim3(nq), dim3(256), lds, s, dists_in, ids_in, shard_stride, nshards, nq,
-                       k, dists_out, ids_out);
+                       k, dists_out, ids_out, cnt_out, ext_ids);
     return hipGetLastError();
 }
 

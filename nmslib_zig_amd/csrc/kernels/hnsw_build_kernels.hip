@@ -11,9 +11,14 @@
 //   3. link      - HnswNode::addFriendlevel (hnsw.h:258-314) target by target: append, or shrink
 //                  with the same heuristic when the list is full.
 // The nodes of one batch do not see each other while searching (like the reference's concurrent
-// inserts, which lock one node at a time); reverse links of a batch are applied per target in
-// ascending new-node order, so the construction is deterministic.  One wavefront per node/target;
-// no workgroup ever waits for another inside a launch.
+// inserts, which lock one node at a time).  Reverse-link requests are written to fixed slots (new node x M),
+// sorted by (target, new node) with one device radix sort, and applied per target in that order: any
+// number of requests per target, no atomics, no dependence on scheduling -> the construction is
+// deterministic.  One wavefront per node/target; no workgroup ever waits for another inside a launch.
+#include <cstring>
+
+#include <rocprim/device/device_radix_sort.hpp>
+
 #include "hnsw_common.cuh"
 #include "kernels.hpp"
 
@@ -30,13 +35,19 @@ struct BuildArgs {
     const float* cand_d;
     const int32_t* cand_n;
     int stride;
-    int32_t* req_cnt;
-    int32_t* req_node;
-    float* req_dist;
-    int req_cap;
-    int32_t* active;
+    u64* req_key;        // select: [npts][M] slots, key = target << 32 | new node (pad = ~0); link: the sorted keys
+    float* req_dist;     // distance(target, new node), same order as req_key
+    int req_total;       // link: number of slots (valid entries sort to the front)
+    int32_t* active;     // link: index of the first request of each target
     int32_t* nactive;
+    // batch-mates (hnsw_build_mates_kernel): per new node up to XCAP earlier nodes of the same batch that are closer
+    // than its worst candidate, ascending by distance
+    int32_t* extra_ids;
+    float* extra_d;
+    int32_t* extra_n;
 };
+
+constexpr int XCAP = 64;
 
 __device__ __forceinline__ int32_t* adj_list(const BuildArgs& a, int node) {
     if (a.level == 0) return a.links0 + (size_t)node * (a.g.maxM0 + 1);
@@ -112,10 +123,45 @@ __global__ __launch_bounds__(64) void hnsw_build_select_kernel(BuildArgs a) {
     float* lc_d = reinterpret_cast<float*>(lc_id + a.stride);   // [stride]
 
     const int p = a.pts[q];
-    const int nc = a.cand_n[q];
-    for (int i = lane; i < nc; i += 64) {
-        lc_id[i] = a.cand_ids[(size_t)q * a.stride + i];
-        lc_d[i] = a.cand_d[(size_t)q * a.stride + i];
+    int nc = a.cand_n[q];
+    const int nx = a.extra_n ? a.extra_n[q] : 0;
+    if (nx == 0) {
+        for (int i = lane; i < nc; i += 64) {
+            lc_id[i] = a.cand_ids[(size_t)q * a.stride + i];
+            lc_d[i] = a.cand_d[(size_t)q * a.stride + i];
+        }
+    } else {
+        // merge the graph-search results with the close batch-mates (both ascending; equal distances: graph
+        // results first), keep the `stride` (= efConstruction) closest: what kSearchElementsWithAttemptsLevel would
+        // have returned had the earlier nodes of this batch already been linked (hnsw.cc:611-708)
+        const float xd = lane < nx ? a.extra_d[(size_t)q * XCAP + lane] : INFINITY;
+        const int xi = lane < nx ? a.extra_ids[(size_t)q * XCAP + lane] : -1;
+        int below = 0;  // graph candidates <= xd
+        for (int base = 0; base < nc; base += 64) {
+            const int i = base + lane;
+            const float cd = i < nc ? a.cand_d[(size_t)q * a.stride + i] : INFINITY;
+            for (int t = 0; t < nx; ++t) {
+                const float xt = __shfl(xd, t, 64);
+                const int c = __popcll(__ballot(i < nc && cd <= xt));
+                if (lane == t) below += c;
+            }
+        }
+        for (int base = 0; base < nc; base += 64) {
+            const int i = base + lane;
+            const float cd = i < nc ? a.cand_d[(size_t)q * a.stride + i] : INFINITY;
+            const int cid = i < nc ? a.cand_ids[(size_t)q * a.stride + i] : -1;
+            int sh = 0;  // batch-mates strictly closer than this candidate (uniform loop: shuffles need every lane)
+            for (int t = 0; t < nx; ++t) sh += (__shfl(xd, t, 64) < cd) ? 1 : 0;
+            if (i < nc && i + sh < a.stride) {
+                lc_id[i + sh] = cid;
+                lc_d[i + sh] = cd;
+            }
+        }
+        if (lane < nx && below + lane < a.stride) {
+            lc_id[below + lane] = xi;
+            lc_d[below + lane] = xd;
+        }
+        nc = nc + nx < a.stride ? nc + nx : a.stride;
     }
     __builtin_amdgcn_wave_barrier();
     const int nk = heuristic2<SPACE>(g, lc_id, lc_d, nc, a.M, a.delaunay, qv, nd, kept_id, kept_d, lane);
@@ -124,16 +170,94 @@ __global__ __launch_bounds__(64) void hnsw_build_select_kernel(BuildArgs a) {
     int32_t* L = adj_list(a, p);
     if (lane == 0) L[0] = nk;
     if (lane < nk) L[1 + lane] = kept_id[nk - 1 - lane];
-    // one reverse-link request per selected neighbour
+    // one reverse-link request per selected neighbour, in this node's own slots
     if (lane < nk) {
-        const int t = kept_id[lane];
-        const int slot = atomicAdd(&a.req_cnt[t], 1);
-        if (slot < a.req_cap) {
-            a.req_node[(size_t)t * a.req_cap + slot] = p;
-            a.req_dist[(size_t)t * a.req_cap + slot] = kept_d[lane];
-        }
-        if (slot == 0) a.active[atomicAdd(a.nactive, 1)] = t;
+        a.req_key[(size_t)q * a.M + lane] = ((u64)(uint32_t)kept_id[lane] << 32) | (uint32_t)p;
+        a.req_dist[(size_t)q * a.M + lane] = kept_d[lane];
     }
+}
+
+// Batch-mates: the nodes of one batch are searched against the graph as it was BEFORE the batch, so a node never meets
+// the earlier nodes of its own batch -- harmless for shuffled data, fatal for data whose insertion order has locality
+// (near-duplicates arriving together end up linked only to their common old neighbours).  This kernel gives node j what
+// sequential insertion gives it: every EARLIER node of the batch (same level slice) that is closer than its worst
+// graph-search candidate, by exhaustive distance evaluation (one wave per node, 32 rows per gather; the batch's rows
+// are L2 / Infinity-Cache resident).  The select kernel merges them into the candidate list.
+template <int SPACE>
+__global__ __launch_bounds__(64) void hnsw_build_mates_kernel(BuildArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const HnswDeviceGraph& g = a.g;
+    const int q = blockIdx.x, lane = threadIdx.x;
+    const int qfloats = DistTraits<SPACE>::kU8 ? 32 : g.ldv;
+    float* qv = reinterpret_cast<float*>(smem);                 // [ldv]
+    int* nbr = reinterpret_cast<int*>(qv + qfloats);            // [32]
+    float* nd = reinterpret_cast<float*>(nbr + 32);             // [32]
+    int* xid = reinterpret_cast<int*>(nd + 32);                 // [XCAP + 32] kept + newly accepted
+    float* xdv = reinterpret_cast<float*>(xid + XCAP + 32);     // [XCAP + 32]
+    int* tid_ = reinterpret_cast<int*>(xdv + XCAP + 32);        // [XCAP + 32] rank-sort scratch
+    float* tdv = reinterpret_cast<float*>(tid_ + XCAP + 32);    // [XCAP + 32]
+
+    int nx = 0;
+    if (q > 0) {
+        const int p = a.pts[q];
+        const int nc = a.cand_n[q];
+        float thr = nc >= a.stride ? a.cand_d[(size_t)q * a.stride + nc - 1] : INFINITY;  // full list: must beat its worst
+        int qnorm;
+        stage_row<SPACE>(g, p, qv, qnorm, lane);
+        for (int base = 0; base < q; base += 32) {
+            const int m = min(32, q - base);
+            if (lane < m) nbr[lane] = a.pts[base + lane];
+            __builtin_amdgcn_wave_barrier();
+            frontier_distances<SPACE>(g, qv, reinterpret_cast<const uint8_t*>(qv), qnorm, nbr, nd, m, lane);
+            const float d = lane < m ? nd[lane] : INFINITY;
+            const bool acc = lane < m && d < thr;
+            const u64 am = __ballot(acc);
+            if (am == 0) continue;
+            const int na = __popcll(am);
+            if (acc) {
+                const int slot = nx + __popcll(am & ((1ull << lane) - 1ull));
+                xid[slot] = nbr[lane];
+                xdv[slot] = d;
+            }
+            __builtin_amdgcn_wave_barrier();
+            // rank-sort the nx + na entries (distance, then arrival order), keep the XCAP closest
+            const int tot = nx + na;
+            for (int i = lane; i < tot; i += 64) {
+                tid_[i] = xid[i];
+                tdv[i] = xdv[i];
+            }
+            __builtin_amdgcn_wave_barrier();
+            for (int i = lane; i < tot; i += 64) {
+                const float di = tdv[i];
+                int r = 0;
+                for (int j = 0; j < tot; ++j) {
+                    const float dj = tdv[j];
+                    r += (dj < di || (dj == di && j < i)) ? 1 : 0;
+                }
+                if (r < XCAP) {
+                    xid[r] = tid_[i];
+                    xdv[r] = di;
+                }
+            }
+            nx = tot < XCAP ? tot : XCAP;
+            __builtin_amdgcn_wave_barrier();
+            if (nx == XCAP) thr = fminf(thr, xdv[XCAP - 1]);
+        }
+    }
+    if (lane == 0) a.extra_n[q] = nx;
+    if (lane < nx) {
+        a.extra_ids[(size_t)q * XCAP + lane] = xid[lane];
+        a.extra_d[(size_t)q * XCAP + lane] = xdv[lane];
+    }
+}
+
+// first request of every target in the sorted list -> active[]
+__global__ void hnsw_build_heads_kernel(const u64* keys, int total, int32_t* active, int32_t* nactive) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const u64 k = keys[i];
+    if (k == ~0ull) return;
+    if (i == 0 || (uint32_t)(keys[i - 1] >> 32) != (uint32_t)(k >> 32)) active[atomicAdd(nactive, 1)] = i;
 }
 
 template <int SPACE>
@@ -152,35 +276,21 @@ __global__ __launch_bounds__(64) void hnsw_build_link_kernel(BuildArgs a) {
     int* sc_id = fl + W;                                        // [W] friends + new node, sorted
     float* sc_d = reinterpret_cast<float*>(sc_id + W);          // [W]
     float* td = sc_d + W;                                       // [W] unsorted distances of the same
-    int* rp = reinterpret_cast<int*>(td + W);                   // [64] requests, sorted by new node
-    float* rd = reinterpret_cast<float*>(rp + 64);              // [64]
 
-    const int t = a.active[blockIdx.x];
-    int nreq = a.req_cnt[t];
-    nreq = nreq < a.req_cap ? nreq : a.req_cap;
-    {   // requests in ascending new-node order (deterministic)
-        int pj = 0x7FFFFFFF;
-        float dj = 0.f;
-        if (lane < nreq) {
-            pj = a.req_node[(size_t)t * a.req_cap + lane];
-            dj = a.req_dist[(size_t)t * a.req_cap + lane];
-        }
-        int rank = 0;
-        for (int i = 0; i < nreq; ++i) rank += (__shfl(pj, i, 64) < pj) ? 1 : 0;
-        if (lane < nreq) {
-            rp[rank] = pj;
-            rd[rank] = dj;
-        }
-    }
+    const int first = a.active[blockIdx.x];
+    const int t = (int)(uint32_t)(a.req_key[first] >> 32);
     int32_t* L = adj_list(a, t);
     const int maxsz = a.level > 0 ? g.maxM : g.maxM0;
     int cnt = L[0];
     for (int i = lane; i < cnt; i += 64) fl[i] = L[1 + i];
     __builtin_amdgcn_wave_barrier();
 
-    for (int r = 0; r < nreq; ++r) {
-        const int p = rp[r];
-        const float dp = rd[r];
+    // this target's requests: consecutive in the sorted list, ascending new-node id
+    for (int r = first; r < a.req_total; ++r) {
+        const u64 rk = a.req_key[r];
+        if ((int)(uint32_t)(rk >> 32) != t || rk == ~0ull) break;
+        const int p = (int)(uint32_t)rk;
+        const float dp = a.req_dist[r];
         if (cnt < maxsz) {
             if (lane == 0) fl[cnt] = p;
             cnt++;
@@ -221,10 +331,7 @@ __global__ __launch_bounds__(64) void hnsw_build_link_kernel(BuildArgs a) {
         cnt = nk;
         __builtin_amdgcn_wave_barrier();
     }
-    if (lane == 0) {
-        L[0] = cnt;
-        a.req_cnt[t] = 0;
-    }
+    if (lane == 0) L[0] = cnt;
     for (int i = lane; i < maxsz; i += 64) L[1 + i] = i < cnt ? fl[i] : 0;
 }
 
@@ -283,8 +390,13 @@ static BuildArgs base_args(const HnswBuildGraph& bg, int level) {
 
 hipError_t launch_hnsw_build_select(const HnswBuildGraph& bg, int level, const int32_t* pts, int npts,
                                     const int32_t* cand_ids, const float* cand_d, const int32_t* cand_n,
-                                    int stride, int32_t* req_cnt, int32_t* req_node, float* req_dist,
-                                    int req_cap, int32_t* active, int32_t* nactive, hipStream_t s) {
+                                    int stride, const int32_t* extra_ids, const float* extra_d,
+                                    const int32_t* extra_n, unsigned long long* req_key, float* req_dist,
+                                    hipStream_t s) {
+    if (npts <= 0) return hipSuccess;
+    // unused slots keep the pad key ~0 and sort behind every real request
+    hipError_t e = hipMemsetAsync(req_key, 0xFF, (size_t)npts * bg.M * 8, s);
+    if (e != hipSuccess) return e;
     BuildArgs a = base_args(bg, level);
     a.pts = pts;
     a.npts = npts;
@@ -292,29 +404,70 @@ hipError_t launch_hnsw_build_select(const HnswBuildGraph& bg, int level, const i
     a.cand_d = cand_d;
     a.cand_n = cand_n;
     a.stride = stride;
-    a.req_cnt = req_cnt;
-    a.req_node = req_node;
+    a.req_key = req_key;
     a.req_dist = req_dist;
-    a.req_cap = req_cap;
-    a.active = active;
-    a.nactive = nactive;
+    a.extra_ids = const_cast<int32_t*>(extra_ids);
+    a.extra_d = const_cast<float*>(extra_d);
+    a.extra_n = const_cast<int32_t*>(extra_n);
     const size_t qbytes = bg.g.space == SP_L2SQR_SIFT ? 128 : (size_t)bg.g.ldv * 4;
     const size_t lds = qbytes + 3 * 64 * 4 + (size_t)stride * 8 + 16;
     BUILD_DISPATCH(hnsw_build_select_kernel, bg.g.space, a, npts, lds, s)
 }
 
+hipError_t launch_hnsw_build_mates(const HnswBuildGraph& bg, int level, const int32_t* pts, int npts,
+                                   const float* cand_d, const int32_t* cand_n, int stride, int32_t* extra_ids,
+                                   float* extra_d, int32_t* extra_n, hipStream_t s) {
+    if (npts <= 0) return hipSuccess;
+    BuildArgs a = base_args(bg, level);
+    a.pts = pts;
+    a.npts = npts;
+    a.cand_d = cand_d;
+    a.cand_n = cand_n;
+    a.stride = stride;
+    a.extra_ids = extra_ids;
+    a.extra_d = extra_d;
+    a.extra_n = extra_n;
+    const size_t qbytes = bg.g.space == SP_L2SQR_SIFT ? 128 : (size_t)bg.g.ldv * 4;
+    const size_t lds = qbytes + 2 * 32 * 4 + 4 * (size_t)(XCAP + 32) * 4 + 16;
+    BUILD_DISPATCH(hnsw_build_mates_kernel, bg.g.space, a, npts, lds, s)
+}
+
+size_t hnsw_build_sort_temp_bytes(int max_requests, int n) {
+    size_t tmp = 0;
+    int bits = 32;
+    while (bits < 64 && (1ull << (bits - 32)) < (unsigned long long)n + 1) ++bits;
+    (void)rocprim::radix_sort_pairs(nullptr, tmp, (unsigned long long*)nullptr, (unsigned long long*)nullptr,
+                                    (float*)nullptr, (float*)nullptr, (size_t)max_requests, 0, 64, nullptr, false);
+    (void)bits;
+    return tmp + 256;
+}
+
+// (target, new node) order of the requests of one level + the first request of every target
+hipError_t launch_hnsw_build_sort_requests(const unsigned long long* req_key, const float* req_dist, int total,
+                                           unsigned long long* key_sorted, float* dist_sorted, void* temp,
+                                           size_t temp_bytes, int32_t* active, int32_t* nactive, hipStream_t s) {
+    if (total <= 0) return hipSuccess;
+    hipError_t e = hipMemsetAsync(nactive, 0, 4, s);
+    if (e != hipSuccess) return e;
+    e = rocprim::radix_sort_pairs(temp, temp_bytes, req_key, key_sorted, req_dist, dist_sorted, (size_t)total, 0, 64, s,
+                                  false);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(hnsw_build_heads_kernel, dim3((total + 255) / 256), dim3(256), 0, s, key_sorted, total, active,
+                       nactive);
+    return hipGetLastError();
+}
+
 hipError_t launch_hnsw_build_link(const HnswBuildGraph& bg, int level, const int32_t* active,
-                                  const int32_t* nactive, int max_active, int32_t* req_cnt,
-                                  const int32_t* req_node, const float* req_dist, int req_cap, hipStream_t s) {
+                                  const int32_t* nactive, int max_active, const unsigned long long* key_sorted,
+                                  const float* dist_sorted, int total, hipStream_t s) {
     BuildArgs a = base_args(bg, level);
     a.active = const_cast<int32_t*>(active);
     a.nactive = const_cast<int32_t*>(nactive);
-    a.req_cnt = req_cnt;
-    a.req_node = const_cast<int32_t*>(req_node);
-    a.req_dist = const_cast<float*>(req_dist);
-    a.req_cap = req_cap;
+    a.req_key = const_cast<u64*>(key_sorted);
+    a.req_dist = const_cast<float*>(dist_sorted);
+    a.req_total = total;
     const size_t qbytes = bg.g.space == SP_L2SQR_SIFT ? 128 : (size_t)bg.g.ldv * 4;
-    const size_t lds = qbytes + (7 * 128 + 2 * 64) * 4 + 16;
+    const size_t lds = qbytes + 7 * 128 * 4 + 16;
     BUILD_DISPATCH(hnsw_build_link_kernel, bg.g.space, a, max_active, lds, s)
 }
 

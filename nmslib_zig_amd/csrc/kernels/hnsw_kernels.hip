@@ -43,6 +43,11 @@ struct HnswArgs {
     int level;
     int table_size, table_shift;
     int prof;  // NMSLIB_HNSW_PROF: accumulate per-phase cycles into g_hnsw_prof (experiments only)
+    // visited-table overflow without the host: the LDS-table launch appends overflowed queries to fix_list; the
+    // bitset launch that follows (fix_mode) walks that list, each workgroup with its own bitset slot
+    int32_t* fix_list;
+    int32_t* fix_count;
+    int fix_mode;
 };
 
 // [0] descent, [1] pick + adjacency, [2] visited filter, [3] gather + distances, [4] accept + sort, [5] inserts, [6] waves
@@ -55,10 +60,9 @@ constexpr int SA_EMAX_MAX = 16;  // sorted array up to 64*16 = 1024 items
 // WIDE: level-0 lists of more than 62 neighbours (maxM0 up to 126, i.e. M >= 32): second adjacency chunk,
 // 128-entry neighbour staging, two insertion rounds.  Kept out of the common instantiation.
 template <int SPACE, bool BITSET, int SA_EMAX, bool WIDE>
-__global__ __launch_bounds__(64) void hnsw_search_kernel(HnswArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+__device__ __forceinline__ void hnsw_search_body(const HnswArgs& a, char* smem, const int q, uint32_t* const bits) {
     const HnswDeviceGraph& g = a.g;
-    const int q = blockIdx.x, lane = threadIdx.x;
+    const int lane = threadIdx.x;
     constexpr bool kU8 = DistTraits<SPACE>::kU8;
 
     // ---- LDS carve-up (all offsets multiples of 16 bytes) ----
@@ -72,7 +76,6 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(HnswArgs a) {
     float* sk = nd + nbcap;                                        // [64] accepted keys, sorted
     int* si = reinterpret_cast<int*>(sk + 64);                     // [64] accepted ids
     uint32_t* table = reinterpret_cast<uint32_t*>(si + 64);        // [table_size]
-    uint32_t* bits = BITSET ? a.bitset + (size_t)q * a.bitset_words : nullptr;
 
     // ---- stage the query ----
     int qnorm = 0;
@@ -497,6 +500,430 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(HnswArgs a) {
         if (a.out_hops) a.out_hops[q] = hops;
         if (a.out_hops_up) a.out_hops_up[q] = hops_up;
         if (a.status) a.status[q] = overflow ? 1 : 0;
+        if (!BITSET && overflow && a.fix_list) a.fix_list[atomicAdd(a.fix_count, 1)] = q;
+    }
+}
+
+template <int SPACE, bool BITSET, int SA_EMAX, bool WIDE>
+__global__ __launch_bounds__(64) void hnsw_search_kernel(HnswArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if constexpr (BITSET) {
+        if (a.fix_mode) {
+            // queries whose LDS visited table filled up in the previous launch, re-run on HBM bitsets: workgroup b
+            // owns bitset slot b and clears it before every query it takes from the list
+            const int cnt = *a.fix_count;
+            uint32_t* bits = a.bitset + (size_t)blockIdx.x * a.bitset_words;
+            for (int slot = blockIdx.x; slot < cnt; slot += gridDim.x) {
+                for (size_t i = threadIdx.x; i < a.bitset_words; i += 64) bits[i] = 0u;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                hnsw_search_body<SPACE, true, SA_EMAX, WIDE>(a, smem, a.fix_list[slot], bits);
+                __builtin_amdgcn_wave_barrier();
+            }
+            return;
+        }
+        hnsw_search_body<SPACE, true, SA_EMAX, WIDE>(a, smem, blockIdx.x, a.bitset + (size_t)blockIdx.x * a.bitset_words);
+    } else {
+        hnsw_search_body<SPACE, false, SA_EMAX, WIDE>(a, smem, blockIdx.x, nullptr);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Hnsw::SearchOld (src/method/hnsw_distfunc_opt.cc:46-150; generic twin baseSearchAlgorithmOld, hnsw.cc:1083-1172):
+// the reference's search for algoType=old and, in hybrid mode, for ef >= 1000 (hnsw.cc:724).  Item for item:
+//   candidateQueuei  - std::priority_queue on -distance.  Its pop order among EQUAL keys depends on the binary-heap
+//                      layout, so the heap is kept as a real array heap with libstdc++'s push_heap / pop_heap moves
+//                      (__adjust_heap walks the larger child down to a leaf, then __push_heap lifts the value);
+//   closestDistQueuei- only its top key and its size are ever observed, so it is kept as the sorted array of its key
+//                      VALUES: neighbour j of an expansion is accepted iff fewer than ef values of (queue + earlier
+//                      neighbours of this expansion) are <= d_j -- the closed form of the sequential
+//                      "top > d || size < ef" test (:126), evaluated for all neighbours at once;
+//   query result     - KNNQueue (knnquery.cc:66-75, knnqueue.h:55-64): strict "d < top", eviction of the largest
+//                      (distance, object address = internal id) pair: a sorted (key, id) array, sequential inserts.
+// No capacity limits: arrays that outgrow LDS live in a per-query HBM workspace (generic pointers).  One wave per
+// query; the frontier gather is the same 8-lanes-per-row kernel as V1Merge.
+// ---------------------------------------------------------------------------------------
+struct OldWs {
+    int capA, capR;          // ef, k
+    int heap_lds;            // heap entries kept in LDS (the top levels); the rest spills to heap_hbm
+    int heap_cap;            // total heap capacity per query; exceeding it sets status 2 (host retries with n)
+    int a_in_lds, r_in_lds;
+    float* a_hbm;            // [nq][capA]      when !a_in_lds
+    u64* r_hbm;              // [nq][capR]      when !r_in_lds
+    u64* heap_hbm;           // [nq][heap_cap - heap_lds]
+};
+
+// the arrays below may live in HBM (generic pointers): make one lane's stores visible to the other lanes of the wave
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+__device__ __forceinline__ u64 pack_kid(float key, int id) { return ((u64)__float_as_uint(key) << 32) | (uint32_t)id; }
+__device__ __forceinline__ float kid_key(u64 v) { return __uint_as_float((uint32_t)(v >> 32)); }
+__device__ __forceinline__ int kid_id(u64 v) { return (int)(uint32_t)v; }
+
+template <int SPACE, bool BITSET, bool WIDE>
+__global__ __launch_bounds__(64) void hnsw_search_old_kernel(HnswArgs a, OldWs w) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const HnswDeviceGraph& g = a.g;
+    const int q = blockIdx.x, lane = threadIdx.x;
+    constexpr bool kU8 = DistTraits<SPACE>::kU8;
+    constexpr int nbcap = WIDE ? 128 : 64;
+
+    // ---- LDS carve-up ----
+    const int qfloats = kU8 ? 32 : g.ldv;
+    float* qv = reinterpret_cast<float*>(smem);                          // [ldv]
+    int* nbr = reinterpret_cast<int*>(qv + qfloats);                      // [nbcap]
+    float* nd = reinterpret_cast<float*>(nbr + nbcap);                    // [nbcap]
+    float* sk = nd + nbcap;                                               // [64] accepted keys, sorted
+    u64* heap_l = reinterpret_cast<u64*>(sk + 64);                        // [heap_lds]
+    float* a_l = reinterpret_cast<float*>(heap_l + w.heap_lds);           // [capA] when in LDS
+    u64* r_l = reinterpret_cast<u64*>(a_l + (w.a_in_lds ? ((w.capA + 1) & ~1) : 0));  // [capR] when in LDS
+    uint32_t* table = reinterpret_cast<uint32_t*>(r_l + (w.r_in_lds ? w.capR : 0));   // [table_size]
+    uint32_t* bits = BITSET ? a.bitset + (size_t)q * a.bitset_words : nullptr;
+    float* A = w.a_in_lds ? a_l : w.a_hbm + (size_t)q * w.capA;
+    u64* R = w.r_in_lds ? r_l : w.r_hbm + (size_t)q * w.capR;
+    u64* heap_g = w.heap_hbm + (size_t)q * (size_t)(w.heap_cap - w.heap_lds);
+    auto hget = [&](int i) -> u64 { return i < w.heap_lds ? heap_l[i] : heap_g[i - w.heap_lds]; };
+    auto hset = [&](int i, u64 v) {
+        if (i < w.heap_lds) heap_l[i] = v;
+        else heap_g[i - w.heap_lds] = v;
+    };
+
+    // ---- stage the query (as the V1Merge kernel) ----
+    int qnorm = 0;
+    if constexpr (kU8) {
+        const uint8_t* src = reinterpret_cast<const uint8_t*>(a.queries) + (size_t)q * 128;
+        const int x0 = src[2 * lane], x1 = src[2 * lane + 1];
+        reinterpret_cast<uint8_t*>(qv)[2 * lane] = (uint8_t)x0;
+        reinterpret_cast<uint8_t*>(qv)[2 * lane + 1] = (uint8_t)x1;
+        qnorm = wave_sum_i(x0 * x0 + x1 * x1);
+    } else {
+        const float* src = reinterpret_cast<const float*>(a.queries) + (size_t)q * g.dim;
+        float ss = 0.f;
+        for (int d = lane; d < g.ldv; d += 64) {
+            const float v = d < g.dim ? src[d] : 0.f;
+            qv[d] = v;
+            ss = fmaf(v, v, ss);
+        }
+        if (g.normalize_query) {  // hnsw_distfunc_opt.cc:55-57
+            ss = wave_sum(ss);
+            if (ss != 0.0f) {
+                const float inv = 1.0f / sqrtf(ss);
+                for (int d = lane; d < g.dim; d += 64) qv[d] *= inv;
+            }
+        }
+    }
+    if constexpr (!BITSET) {
+        for (int i = lane; i < a.table_size; i += 64) table[i] = HT_EMPTY;
+    }
+    __builtin_amdgcn_wave_barrier();
+    const uint8_t* qb = reinterpret_cast<const uint8_t*>(qv);
+
+    auto visit = [&](uint32_t id) -> bool {
+        if constexpr (BITSET) {
+            const uint32_t bit = 1u << (id & 31);
+            const uint32_t old = atomicOr(&bits[id >> 5], bit);
+            return (old & bit) == 0;
+        } else {
+            uint32_t hsh = (id * 2654435761u) >> a.table_shift;
+            const uint32_t mask = (uint32_t)a.table_size - 1u;
+            for (int probe = 0; probe < a.table_size; ++probe) {
+                const uint32_t old = atomicCAS(&table[hsh], HT_EMPTY, id);
+                if (old == HT_EMPTY) return true;
+                if (old == id) return false;
+                hsh = (hsh + 1) & mask;
+            }
+            return false;
+        }
+    };
+
+    int ndc = 0, hops = 0, hops_up = 0, nvisited = 0, status = 0;
+    if (g.n == 0) {
+        for (int i = lane; i < a.k; i += 64) {
+            a.out_ids[(size_t)q * a.k + i] = -1;
+            a.out_dists[(size_t)q * a.k + i] = INFINITY;
+        }
+        if (lane == 0) {
+            a.out_cnt[q] = 0;
+            if (a.out_ndc) a.out_ndc[q] = 0;
+            if (a.out_hops) a.out_hops[q] = 0;
+            if (a.out_hops_up) a.out_hops_up[q] = 0;
+            if (a.status) a.status[q] = 0;
+        }
+        return;
+    }
+
+    // ---- entry point + greedy descent (:64-92) ----
+    int cur = g.enterpoint;
+    if (lane == 0) nbr[0] = cur;
+    __builtin_amdgcn_wave_barrier();
+    frontier_distances<SPACE>(g, qv, qb, qnorm, nbr, nd, 1, lane);
+    float curdist = nd[0];
+    ndc += 1;
+    for (int lvl = g.maxlevel; lvl > 0; --lvl) {
+        bool changed = true;
+        while (changed) {
+            changed = false;
+            const int64_t off = g.up_off[cur] + (int64_t)(lvl - 1) * (g.maxM + 1);
+            const int v = (lane <= g.maxM) ? g.up_links[off + lane] : 0;
+            const int cntl = __builtin_amdgcn_readfirstlane(v);
+            const int nb = __shfl(v, lane + 1, 64);
+            if (lane < cntl) nbr[lane] = nb;
+            __builtin_amdgcn_wave_barrier();
+            hops_up++;
+            if (cntl > 0) {
+                frontier_distances<SPACE>(g, qv, qb, qnorm, nbr, nd, cntl, lane);
+                ndc += cntl;
+                u64 key = ~0ull;
+                if (lane < cntl) key = ((u64)f32_ord(nd[lane]) << 32) | (uint32_t)lane;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    const u64 other = __shfl_xor(key, o, 64);
+                    key = other < key ? other : key;
+                }
+                const float dmin = ord_f32((uint32_t)(key >> 32));
+                if (dmin < curdist) {
+                    curdist = dmin;
+                    cur = nbr[(uint32_t)key];
+                    changed = true;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+
+    // ---- level 0 (:94-147) ----
+    int nA = 1, nR = 1, hn = 1;
+    if (lane == 0) {
+        A[0] = curdist;
+        R[0] = pack_kid(curdist, cur);
+        hset(0, pack_kid(curdist, cur));
+        (void)visit((uint32_t)cur);
+    }
+    nvisited = 1;
+    wave_sync();
+
+    // std::push_heap of (key, id) at the end of the candidate heap.  comp(parent, value) on -distance
+    // <=> parent.key > value.key: such parents move down.  Lane L looks at ancestor L of the new slot.
+    auto heap_push = [&](float key, int id) {
+        const int hole = hn;
+        hn++;
+        const int j = hole + 1;  // 1-based
+        const int jl = lane < 31 ? (j >> lane) : 0;  // 1-based index of ancestor `lane` levels up (0 = none)
+        const bool has = lane >= 1 && jl >= 1;
+        const int anc = has ? jl - 1 : 0;
+        const u64 av = has ? hget(anc) : 0ull;
+        const bool moves = has && kid_key(av) > key;
+        // first lane >= 1 whose ancestor does not move (or does not exist) ends the walk
+        const u64 stop = __ballot(!moves) & ~1ull;
+        const int sL = __ffsll((long long)stop) - 1;  // >= 1 (lane 63 never has an ancestor for heaps < 2^62)
+        if (lane >= 1 && lane < sL) hset((j >> (lane - 1)) - 1, av);
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) hset((j >> (sL - 1)) - 1, pack_kid(key, id));
+        wave_sync();
+    };
+    // std::pop_heap + pop_back (libstdc++ __adjust_heap): the hole walks down along the larger child (on -distance:
+    // the child with the SMALLER key; equal keys -> the right child) to a leaf, then the last element is pushed up.
+    auto heap_pop = [&]() {
+        if (hn <= 1) {
+            hn = 0;
+            return;
+        }
+        const int len = hn - 1;
+        const u64 val = hget(len);
+        int hole = 0, child = 0;
+        while (child < (len - 1) / 2) {
+            child = 2 * (child + 1);
+            const u64 cr = hget(child), cl = hget(child - 1);
+            u64 cv = cr;
+            if (kid_key(cr) > kid_key(cl)) {
+                child--;
+                cv = cl;
+            }
+            if (lane == 0) hset(hole, cv);
+            hole = child;
+        }
+        if ((len & 1) == 0 && child == (len - 2) / 2) {
+            child = 2 * (child + 1);
+            if (lane == 0) hset(hole, hget(child - 1));
+            hole = child - 1;
+        }
+        wave_sync();
+        // __push_heap(first, hole, top = 0, val)
+        hn = hole;  // heap_push appends at `hn`
+        heap_push(kid_key(val), kid_id(val));
+        hn = len;
+    };
+
+    while (hn > 0) {
+        const u64 top = hget(0);
+        const float lower = A[nA - 1];
+        if (kid_key(top) > lower) break;  // :107-109
+        heap_pop();
+        const int c = kid_id(top);
+        hops++;
+        // adjacency [count][ids...]
+        const int v = (lane <= g.maxM0) ? g.links0[(size_t)c * (g.maxM0 + 1) + lane] : 0;
+        const int cntn = __builtin_amdgcn_readfirstlane(v);
+        const int nb = __shfl(v, lane + 1, 64);
+        bool isn = false;
+        if (lane < cntn && (!WIDE || lane < 63)) isn = visit((uint32_t)nb);
+        const u64 nmask = __ballot(isn);
+        int m = __popcll(nmask);
+        if (isn) nbr[__popcll(nmask & ((1ull << lane) - 1ull))] = nb;
+        if (WIDE && cntn > 63) {
+            int nb2 = 0;
+            if (64 + lane <= g.maxM0) nb2 = g.links0[(size_t)c * (g.maxM0 + 1) + 64 + lane];
+            bool isn2 = false;
+            if (63 + lane < cntn) isn2 = visit((uint32_t)nb2);
+            const u64 nmask2 = __ballot(isn2);
+            if (isn2) nbr[m + __popcll(nmask2 & ((1ull << lane) - 1ull))] = nb2;
+            m += __popcll(nmask2);
+        }
+        nvisited += m;
+        if (!BITSET && nvisited > (a.table_size - (a.table_size >> 3))) {
+            status = 1;  // visited table nearly full: the host re-runs with a bitset
+            break;
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (m == 0) continue;
+        ndc += m;
+        frontier_distances<SPACE>(g, qv, qb, qnorm, nbr, nd, m, lane);
+
+        for (int r0 = 0; r0 < m; r0 += 64) {  // list order; one trip unless the lists are wide
+            const bool valid = r0 + lane < m;
+            const float dj = valid ? nd[r0 + lane] : INFINITY;
+            const int idj = valid ? nbr[r0 + lane] : -1;
+            // #{a in A : a <= dj}: upper bound by bisection
+            int lo = 0, hi = nA;
+            while (__any(lo < hi)) {
+                const int mid = (lo + hi) >> 1;
+                const float av = (lo < hi) ? A[mid] : 0.f;
+                if (lo < hi) {
+                    if (av <= dj) lo = mid + 1;
+                    else hi = mid;
+                }
+            }
+            int cnt = lo;
+            u64 vmask = __ballot(valid);
+            for (u64 mm = vmask; mm;) {
+                const int j = __ffsll((long long)mm) - 1;
+                mm &= mm - 1;
+                const float dother = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dj), j));
+                cnt += (j < lane && dother <= dj) ? 1 : 0;
+            }
+            const bool acc = valid && cnt <= a.ef - 1;
+            const u64 amask = __ballot(acc);
+            const int m2 = __popcll(amask);
+            if (m2 == 0) continue;
+
+            // --- closestDistQueue values: merge the accepted keys, keep the ef smallest ---
+            int rank = 0;
+            for (u64 mm = amask; mm;) {
+                const int j = __ffsll((long long)mm) - 1;
+                mm &= mm - 1;
+                const float dother = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dj), j));
+                rank += (dother < dj || (dother == dj && j < lane)) ? 1 : 0;
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (acc) sk[rank] = dj;
+            __builtin_amdgcn_wave_barrier();
+            const int newn = nA + m2 < a.ef ? nA + m2 : a.ef;
+            // old element i moves up by the number of new keys strictly below it; chunks from the top down so
+            // that a chunk is read before anything lands on it
+            for (int base = ((nA - 1) / 64) * 64; base >= 0; base -= 64) {
+                const int i = base + lane;
+                float av = 0.f;
+                int sh = 0;
+                if (i < nA) {
+                    av = A[i];
+                    int l2 = 0, h2 = m2;
+                    while (l2 < h2) {  // #{sk < av}
+                        const int mid = (l2 + h2) >> 1;
+                        if (sk[mid] < av) l2 = mid + 1;
+                        else h2 = mid;
+                    }
+                    sh = l2;
+                }
+                wave_sync();
+                if (i < nA && sh > 0 && i + sh < newn) A[i + sh] = av;
+                wave_sync();
+            }
+            // new key: behind the old keys <= it (`lo`, counted before the moves) plus its rank among the accepted
+            __builtin_amdgcn_wave_barrier();
+            if (acc) {
+                const int np = lo + rank;
+                if (np < newn) A[np] = dj;
+            }
+            nA = newn;
+            wave_sync();
+
+            // --- candidate heap + result queue: accepted neighbours in list order (:127-131) ---
+            for (u64 mm = amask; mm;) {
+                const int j = __ffsll((long long)mm) - 1;
+                mm &= mm - 1;
+                const float key = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dj), j));
+                const int id = __builtin_amdgcn_readlane(idj, j);
+                if (hn >= w.heap_cap) {
+                    status = 2;
+                    break;
+                }
+                heap_push(key, id);
+                // KNNQuery::CheckAndAddToResult
+                const bool full = nR >= a.k;
+                if (full && !(key < kid_key(R[nR - 1]))) continue;
+                // position by (key, id): pair<dist, Object*> ordering
+                int p = 0;
+                for (int base = 0; base < nR; base += 64) {
+                    const int i = base + lane;
+                    bool less = false;
+                    if (i < nR) {
+                        const u64 rv = R[i];
+                        const float rk = kid_key(rv);
+                        less = rk < key || (rk == key && kid_id(rv) < id);
+                    }
+                    p += __popcll(__ballot(less));
+                }
+                const int newr = full ? nR : nR + 1;
+                for (int base = ((newr - 1) / 64) * 64; base >= 0; base -= 64) {
+                    const int i = base + lane;
+                    u64 rv = 0;
+                    const bool mv = i > p && i < newr;
+                    if (mv) rv = R[i - 1];
+                    wave_sync();
+                    if (mv) R[i] = rv;
+                    wave_sync();
+                }
+                if (lane == 0) R[p] = pack_kid(key, id);
+                nR = newr;
+                wave_sync();
+            }
+            if (status) break;
+        }
+        if (status) break;
+    }
+
+    const int kk = status ? 0 : nR;
+    for (int i = lane; i < a.k; i += 64) {
+        if (i < kk) {
+            const u64 rv = R[i];
+            const int id = kid_id(rv);
+            a.out_ids[(size_t)q * a.k + i] = g.ext_ids ? g.ext_ids[id] : id;
+            a.out_dists[(size_t)q * a.k + i] = kid_key(rv);
+        } else {
+            a.out_ids[(size_t)q * a.k + i] = -1;
+            a.out_dists[(size_t)q * a.k + i] = INFINITY;
+        }
+    }
+    if (lane == 0) {
+        a.out_cnt[q] = kk;
+        if (a.out_ndc) a.out_ndc[q] = ndc;
+        if (a.out_hops) a.out_hops[q] = hops;
+        if (a.out_hops_up) a.out_hops_up[q] = hops_up;
+        if (a.status) a.status[q] = status;
     }
 }
 
@@ -545,7 +972,7 @@ static hipError_t launch_space_w(const HnswArgs& a, const HnswSearchPlan& p, hip
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(kern, dim3(a.nq), dim3(64), p.lds_bytes, s, a);
+        hipLaunchKernelGGL(kern, dim3(a.fix_mode ? a.fix_mode : a.nq), dim3(64), p.lds_bytes, s, a);
     } else {
         auto kern = hnsw_search_kernel<SPACE, false, EMAX, WIDE>;
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -569,6 +996,11 @@ static hipError_t launch_space(const HnswArgs& a, const HnswSearchPlan& p, hipSt
     return launch_space_e<SPACE, SA_EMAX_MAX>(a, p, s);
 }
 
+// overflow-list arguments of the launch in progress on this thread (launch_hnsw_search_fix)
+static thread_local int32_t* t_fix_list = nullptr;
+static thread_local int32_t* t_fix_count = nullptr;
+static thread_local int t_fix_mode = 0;
+
 hipError_t launch_hnsw_search_ex(const HnswDeviceGraph& g, const HnswSearchPlan& p, const void* queries,
                                  const int32_t* query_rows, const int32_t* start_nodes, int level,
                               uint32_t* bitset, int32_t* out_ids, float* out_dists, int32_t* out_cnt,
@@ -591,6 +1023,9 @@ hipError_t launch_hnsw_search_ex(const HnswDeviceGraph& g, const HnswSearchPlan&
     a.out_hops = out_hops;
     a.out_hops_up = out_hops_up;
     a.status = status;
+    a.fix_list = t_fix_list;
+    a.fix_count = t_fix_count;
+    a.fix_mode = (p.table_size == 0) ? t_fix_mode : 0;
     static const int prof = getenv("NMSLIB_HNSW_PROF") ? atoi(getenv("NMSLIB_HNSW_PROF")) : 0;
     a.prof = (prof && !query_rows) ? 1 : 0;
     a.nq = p.nq;
@@ -628,12 +1063,124 @@ hipError_t launch_hnsw_search_ex(const HnswDeviceGraph& g, const HnswSearchPlan&
     }
 }
 
+hipError_t launch_hnsw_search_fix(const HnswDeviceGraph& g, const HnswSearchPlan& p, const void* queries,
+                                  uint32_t* bitset, int fix_slots, int32_t* fix_list, int32_t* fix_count,
+                                  int32_t* out_ids, float* out_dists, int32_t* out_cnt, int32_t* out_ndc,
+                                  int32_t* out_hops, int32_t* out_hops_up, int32_t* status, hipStream_t s) {
+    t_fix_list = fix_list;
+    t_fix_count = fix_count;
+    t_fix_mode = fix_slots;
+    const hipError_t e = launch_hnsw_search_ex(g, p, queries, nullptr, nullptr, 0, bitset, out_ids, out_dists, out_cnt,
+                                               out_ndc, out_hops, out_hops_up, status, s);
+    t_fix_list = nullptr;
+    t_fix_count = nullptr;
+    t_fix_mode = 0;
+    return e;
+}
+
 hipError_t launch_hnsw_search(const HnswDeviceGraph& g, const HnswSearchPlan& p, const void* queries,
                               uint32_t* bitset, int32_t* out_ids, float* out_dists, int32_t* out_cnt,
                               int32_t* out_ndc, int32_t* out_hops, int32_t* out_hops_up, int32_t* status,
                               hipStream_t s) {
     return launch_hnsw_search_ex(g, p, queries, nullptr, nullptr, 0, bitset, out_ids, out_dists, out_cnt, out_ndc,
                                  out_hops, out_hops_up, status, s);
+}
+
+// ---- SearchOld ---------------------------------------------------------------------------------------------------
+HnswSearchPlan hnsw_make_plan_old(const HnswDeviceGraph& g, int nq, int k, int ef, bool force_bitset, int heap_cap) {
+    HnswSearchPlan p{};
+    p.nq = nq;
+    p.k = k;
+    p.ef = ef;
+    p.cap = ef > k ? ef : k;
+    const bool u8 = g.space == SP_L2SQR_SIFT;
+    p.a_in_lds = ef <= 8192;
+    p.r_in_lds = k <= 2048;
+    // accepted items are a fraction of the evaluated ones (~18 per unit of ef on 1M-row graphs)
+    long long hc = heap_cap > 0 ? heap_cap : 32ll * p.cap + 4096;
+    if (hc > (long long)g.n + 1) hc = (long long)g.n + 1;
+    p.heap_cap = (int)hc;
+    p.heap_lds = p.heap_cap < 2048 ? p.heap_cap : 2048;
+    const int nbcap = g.maxM0 > 62 ? 128 : 64;
+    const size_t fixed = (u8 ? 128 : (size_t)g.ldv * 4) + (size_t)(2 * nbcap + 64) * 4 + (size_t)p.heap_lds * 8 +
+                         (p.a_in_lds ? (size_t)((ef + 1) & ~1) * 4 : 0) + (p.r_in_lds ? (size_t)k * 8 : 0);
+    int want = 1 << ilog2((g.maxM0 > 0 ? g.maxM0 : 32) * p.cap * 2);
+    if (want < 2048) want = 2048;
+    const size_t budget = 64 * 1024;
+    while ((size_t)want * 4 + fixed > budget && want > 2048) want >>= 1;
+    if (force_bitset || 18 * p.cap > want / 2 || (size_t)want * 4 + fixed > budget) {
+        p.table_size = 0;
+        p.bitset_words = ((size_t)g.n + 31) / 32;
+        p.lds_bytes = fixed + 16;
+    } else {
+        p.table_size = want;
+        p.bitset_words = 0;
+        p.lds_bytes = fixed + (size_t)want * 4;
+    }
+    return p;
+}
+
+template <int SPACE>
+static hipError_t launch_old_space(const HnswArgs& a, const OldWs& w, const HnswSearchPlan& p, hipStream_t s) {
+    auto go = [&](auto kern) -> hipError_t {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)p.lds_bytes);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, dim3(a.nq), dim3(64), p.lds_bytes, s, a, w);
+        return hipGetLastError();
+    };
+    const bool wide = a.g.maxM0 > 62;
+    if (p.table_size == 0) return wide ? go(hnsw_search_old_kernel<SPACE, true, true>) : go(hnsw_search_old_kernel<SPACE, true, false>);
+    return wide ? go(hnsw_search_old_kernel<SPACE, false, true>) : go(hnsw_search_old_kernel<SPACE, false, false>);
+}
+
+hipError_t launch_hnsw_search_old(const HnswDeviceGraph& g, const HnswSearchPlan& p, const void* queries,
+                                  uint32_t* bitset, void* ws_a, void* ws_r, void* ws_heap, int32_t* out_ids,
+                                  float* out_dists, int32_t* out_cnt, int32_t* out_ndc, int32_t* out_hops,
+                                  int32_t* out_hops_up, int32_t* status, hipStream_t s) {
+    if (p.nq == 0) return hipSuccess;
+    if (g.maxM0 > 126 || g.maxM > 62) return hipErrorInvalidValue;
+    HnswArgs a{};
+    a.g = g;
+    a.queries = queries;
+    a.level = 0;
+    a.bitset = bitset;
+    a.bitset_words = p.bitset_words;
+    a.out_ids = out_ids;
+    a.out_dists = out_dists;
+    a.out_cnt = out_cnt;
+    a.out_ndc = out_ndc;
+    a.out_hops = out_hops;
+    a.out_hops_up = out_hops_up;
+    a.status = status;
+    a.nq = p.nq;
+    a.k = p.k;
+    a.ef = p.ef;
+    a.cap = p.cap;
+    a.table_size = p.table_size;
+    a.table_shift = p.table_size ? 32 - ilog2(p.table_size) : 0;
+    OldWs w{};
+    w.capA = p.ef;
+    w.capR = p.k;
+    w.heap_lds = p.heap_lds;
+    w.heap_cap = p.heap_cap;
+    w.a_in_lds = p.a_in_lds;
+    w.r_in_lds = p.r_in_lds;
+    w.a_hbm = static_cast<float*>(ws_a);
+    w.r_hbm = static_cast<u64*>(ws_r);
+    w.heap_hbm = static_cast<u64*>(ws_heap);
+    switch (g.space) {
+        case SP_L2SQR: return launch_old_space<SP_L2SQR>(a, w, p, s);
+        case SP_L2: return launch_old_space<SP_L2>(a, w, p, s);
+        case SP_L1: return launch_old_space<SP_L1>(a, w, p, s);
+        case SP_LINF: return launch_old_space<SP_LINF>(a, w, p, s);
+        case SP_NORMCOS: return launch_old_space<SP_NORMCOS>(a, w, p, s);
+        case SP_COSINE: return launch_old_space<SP_COSINE>(a, w, p, s);
+        case SP_ANGULAR: return launch_old_space<SP_ANGULAR>(a, w, p, s);
+        case SP_NEGDOT: return launch_old_space<SP_NEGDOT>(a, w, p, s);
+        case SP_L2SQR_SIFT: return launch_old_space<SP_L2SQR_SIFT>(a, w, p, s);
+        default: return hipErrorInvalidValue;
+    }
 }
 
 }  // namespace gfxknn

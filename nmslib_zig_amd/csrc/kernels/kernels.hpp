@@ -63,10 +63,22 @@ hipError_t launch_pad_rows(const void* src, int rows, int dim, void* dst, int ro
 // In-place L2 normalisation of rows (hnsw.cc:441-446, hnsw.h:486-497).
 hipError_t launch_normalize_rows(float* rows, int n, int ld, int dim, hipStream_t s);
 
+// Column sums in f64: stats[0..ldb) = per-column sums, stats[ldb] = sum of squares of all elements.
+hipError_t launch_col_stats(const float* base, int n, int ldb, int dim, double* stats, hipStream_t s);
+// dst = src - mean (columns < dim of the first rows_valid rows); used for the centred L2 selection copy and its queries.
+hipError_t launch_center_rows(const float* src, const float* mean, int rows, int rows_valid, int ld, int dim, float* dst,
+                              hipStream_t s);
+
 // ---- brute force: selection (MFMA) + exact re-rank ---------------------------------------
+// qaux_cosc != NULL (cosine / angular only): base and queries are CENTRED copies, aux holds three planes
+// (launch_row_aux_cosc) and qaux_cosc the per-query constants (launch_query_aux_cosc).
 hipError_t launch_bf_select_f32(const BfPlan& p, int space, const float* base, const float* aux,
-                                const float* queries_padded, unsigned long long* cand,
+                                const float* queries_padded, const float* qaux_cosc, unsigned long long* cand,
                                 int* cand_cnt, hipStream_t s);
+hipError_t launch_row_aux_cosc(const float* orig, const float* centred, int n, int ldb, int dim, double mu_norm, float* aux,
+                               hipStream_t s);
+hipError_t launch_query_aux_cosc(const float* orig, const float* centred, int nq, int ldb, int dim, double mu_norm,
+                                 float* qaux, hipStream_t s);
 hipError_t launch_bf_select_u8(const BfPlan& p, const uint8_t* base_i8, const int32_t* aux,
                                const uint8_t* queries_padded, unsigned long long* cand,
                                int* cand_cnt, hipStream_t s);
@@ -102,8 +114,22 @@ struct HnswSearchPlan {
     int table_size;            // LDS visited hash entries (power of two); 0 -> global bitset
     size_t lds_bytes;
     size_t bitset_words;       // per query, when table_size == 0
+    // SearchOld kernel only (hnsw_make_plan_old): candidate heap and queue placement
+    int heap_lds, heap_cap;    // heap entries in LDS / in total per query (the rest lives in the HBM workspace)
+    int a_in_lds, r_in_lds;    // closest-queue values (ef floats) / result queue (k pairs) in LDS?
 };
 HnswSearchPlan hnsw_make_plan(const HnswDeviceGraph& g, int nq, int k, int ef, bool force_bitset);
+// Plan of the SearchOld kernel (hnsw_distfunc_opt.cc:46-150): no limit on ef or k.  heap_cap = 0 picks the default
+// bound on the candidate heap (queries that outgrow it report status 2 and are retried with heap_cap = n).
+HnswSearchPlan hnsw_make_plan_old(const HnswDeviceGraph& g, int nq, int k, int ef, bool force_bitset, int heap_cap);
+// per-query HBM workspace of the SearchOld kernel, in bytes (0 = nothing spills)
+inline size_t hnsw_old_ws_a(const HnswSearchPlan& p) { return p.a_in_lds ? 0 : (size_t)p.ef * 4; }
+inline size_t hnsw_old_ws_r(const HnswSearchPlan& p) { return p.r_in_lds ? 0 : (size_t)p.k * 8; }
+inline size_t hnsw_old_ws_heap(const HnswSearchPlan& p) { return (size_t)(p.heap_cap - p.heap_lds) * 8; }
+hipError_t launch_hnsw_search_old(const HnswDeviceGraph& g, const HnswSearchPlan& p, const void* queries,
+                                  uint32_t* bitset, void* ws_a, void* ws_r, void* ws_heap, int32_t* out_ids,
+                                  float* out_dists, int32_t* out_cnt, int32_t* out_ndc, int32_t* out_hops,
+                                  int32_t* out_hops_up, int32_t* status, hipStream_t s);
 // queries: [nq][dim] f32 (row stride dim) or u8 [nq][128].  status[q] != 0 -> visited table
 // overflowed (caller re-runs those with the bitset variant).
 hipError_t launch_hnsw_search(const HnswDeviceGraph& g, const HnswSearchPlan& p,
@@ -111,6 +137,15 @@ hipError_t launch_hnsw_search(const HnswDeviceGraph& g, const HnswSearchPlan& p,
                               float* out_dists, int32_t* out_cnt, int32_t* out_ndc,
                               int32_t* out_hops, int32_t* out_hops_up, int32_t* status,
                               hipStream_t s);
+
+// Visited-table overflow handled on the device (no host round trip):
+//   1. LDS-table plan:  fix_slots = 0, fix_list/fix_count given -> overflowed queries are appended to fix_list;
+//   2. bitset plan:     fix_slots = S > 0 -> S workgroups walk fix_list (count read on the device), each clearing and
+//      using its own bitset slot (bitset must hold S * bitset_words words) and overwriting those queries' outputs.
+hipError_t launch_hnsw_search_fix(const HnswDeviceGraph& g, const HnswSearchPlan& p, const void* queries,
+                                  uint32_t* bitset, int fix_slots, int32_t* fix_list, int32_t* fix_count,
+                                  int32_t* out_ids, float* out_dists, int32_t* out_cnt, int32_t* out_ndc,
+                                  int32_t* out_hops, int32_t* out_hops_up, int32_t* status, hipStream_t s);
 
 // Construction-mode search (hnsw_build): queries are stored rows (query_rows), the best-first phase runs on
 // `level`, start_nodes[q] >= 0 gives the start node (else descend from the entry point to level+1).
@@ -131,16 +166,27 @@ struct HnswBuildGraph {          // mutable twin of HnswDeviceGraph
 hipError_t launch_hnsw_build_starts(const int32_t* src, const int32_t* cand_ids, const int32_t* cand_n, int stride,
                                     int32_t* starts, int m, hipStream_t s);
 // Heuristic neighbour selection for the `npts` new nodes listed in pts at `level`: reads the sorted candidates
-// (cand_ids/cand_d/cand_n, stride `stride`), writes each new node's forward list, queues one reverse-link
-// request per selected neighbour (req_*: per-target slots, `req_cap` each; active/nactive: targets touched).
+// (cand_ids/cand_d/cand_n, stride `stride`), writes each new node's forward list, and one reverse-link request per
+// selected neighbour into the node's own M slots: req_key [npts][M] = target << 32 | new node (unused: ~0), req_dist.
 hipError_t launch_hnsw_build_select(const HnswBuildGraph& bg, int level, const int32_t* pts, int npts,
                                     const int32_t* cand_ids, const float* cand_d, const int32_t* cand_n,
-                                    int stride, int32_t* req_cnt, int32_t* req_node, float* req_dist,
-                                    int req_cap, int32_t* active, int32_t* nactive, hipStream_t s);
-// Apply the queued reverse links target by target (addFriendlevel + shrink, hnsw.h:258-314); resets req_cnt.
+                                    int stride, const int32_t* extra_ids, const float* extra_d,
+                                    const int32_t* extra_n, unsigned long long* req_key, float* req_dist,
+                                    hipStream_t s);
+// Batch-mates: for every new node of the level slice, the EARLIER nodes of the slice that are closer than its worst
+// candidate (at most 64, ascending): extra_ids/extra_d [npts][64], extra_n [npts].  Merged by the select kernel.
+hipError_t launch_hnsw_build_mates(const HnswBuildGraph& bg, int level, const int32_t* pts, int npts,
+                                   const float* cand_d, const int32_t* cand_n, int stride, int32_t* extra_ids,
+                                   float* extra_d, int32_t* extra_n, hipStream_t s);
+// Device radix sort of the requests by (target, new node) + the index of each target's first request (active/nactive).
+size_t hnsw_build_sort_temp_bytes(int max_requests, int n);
+hipError_t launch_hnsw_build_sort_requests(const unsigned long long* req_key, const float* req_dist, int total,
+                                           unsigned long long* key_sorted, float* dist_sorted, void* temp,
+                                           size_t temp_bytes, int32_t* active, int32_t* nactive, hipStream_t s);
+// Apply the sorted reverse links target by target (addFriendlevel + shrink, hnsw.h:258-314), any number per target.
 hipError_t launch_hnsw_build_link(const HnswBuildGraph& bg, int level, const int32_t* active,
-                                  const int32_t* nactive, int max_active, int32_t* req_cnt,
-                                  const int32_t* req_node, const float* req_dist, int req_cap, hipStream_t s);
+                                  const int32_t* nactive, int max_active, const unsigned long long* key_sorted,
+                                  const float* dist_sorted, int total, hipStream_t s);
 
 // ---- range search on the brute-force index (range_kernels.hip) ----------------------------------
 // dist_ws: [n] floats; count_ws: [ceil(n/1024) + 1] ints, the last one receives the number of matches.
@@ -154,5 +200,10 @@ hipError_t launch_range_search(int space, const void* rows, int ld, int n, const
 // shard s's lists start at dists_in + s*shard_stride / ids_in + s*shard_stride (elements)
 hipError_t launch_merge_topk(const float* dists_in, const int32_t* ids_in, size_t shard_stride, int nshards, int nq,
                              int k, float* dists_out, int32_t* ids_out, hipStream_t s);
+// ... with the number of valid results per query (cnt_out, optional) and a final id map: ids in the lists are
+// positions, ids_out[i] = ext_ids[position] (ext_ids optional)
+hipError_t launch_merge_topk_ex(const float* dists_in, const int32_t* ids_in, size_t shard_stride, int nshards, int nq,
+                                int k, float* dists_out, int32_t* ids_out, int32_t* cnt_out, const int32_t* ext_ids,
+                                hipStream_t s);
 
 }  // namespace gfxknn

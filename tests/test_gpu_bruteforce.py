@@ -280,3 +280,40 @@ def test_batches_larger_than_one_slice_are_sliced_transparently():
             np.testing.assert_array_equal(ds[lo:lo + 50], d2)
             np.testing.assert_array_equal(cnt[lo:lo + 50], c2)
         idx.close()
+
+
+@pytest.mark.parametrize("offset", [100.0, 1000.0, 10000.0])
+@pytest.mark.parametrize("space", FLOAT_SPACES)
+def test_uncentred_data(space, offset):
+    """Rows with a large common offset: the Q.B^T selection score must not lose neighbours
+    that the reference's direct formulas (distcomp_lp.cc:304-371, distcomp_scalar.cc:83-271) keep.  L2 selection
+    runs on a centred copy, cosine / angular on the centred form of 1 - cos.  Recall is NMSLIB's tie-extended recall
+    against the oracle's exact scan.  Cosine / angular at offsets >= 1000: the reference formula itself
+    (dot / sqrt / sqrt in f32) resolves similarities only to a few 2^-24, which is then the size of the gaps between
+    neighbours, so there the check is against the exact (f64) ranking within that resolution."""
+    n, D, nq, k = 50000, 128, 64, 10
+    X = (refio.s_lowrank(n, D, 61) + np.float32(offset)).astype(np.float32)
+    Q = (refio.s_lowrank(nq, D, 62) + np.float32(offset)).astype(np.float32)
+    idx = make_index(space, "seq_search", X)
+    ids, ds, cnt = idx.knnQueryBatch(Q, k)
+    idx.close()
+    opos, odist, _ = orc.seq_search(space, X, Q, k + 22)
+    # (acos amplifies one ulp of the similarity by 1/theta: angular distances are resolution-limited from offset 100 on)
+    noisy = (space == "cosinesimil" and offset >= 1000) or (space == "angulardist" and offset >= 100)
+    if not noisy:
+        rec = refio.recall_nmslib(ids, opos, odist, k)
+        assert rec >= 0.999, f"{space} offset {offset}: recall {rec}"
+        # returned distances are the reference formula on the ORIGINAL rows
+        assert close_rel(ds, odist[:, :k], rtol=1e-5, atol=1e-6 * max(1.0, offset if space == "negdotprod" else 1.0))
+        return
+    Xd, Qd = X.astype(np.float64), Q.astype(np.float64)
+    sim = (Qd @ Xd.T) / np.linalg.norm(Qd, axis=1)[:, None] / np.linalg.norm(Xd, axis=1)[None, :]
+    res = 4.0 * 2.0 ** -24                                            # resolution of the reference's f32 similarity
+    kth = -np.sort(-sim, axis=1)[:, k - 1]
+    got_sim = np.take_along_axis(sim, ids.astype(np.int64), axis=1)
+    assert (ids >= 0).all() and all(len(set(r)) == k for r in ids.tolist())
+    assert (got_sim >= kth[:, None] - res).mean() >= 0.999, f"{space} offset {offset}"
+    # distances: the reference formula's value of each returned pair, within the same resolution
+    want_sim = got_sim.astype(np.float32)
+    have_sim = np.cos(ds.astype(np.float64)) if space == "angulardist" else 1.0 - ds.astype(np.float64)
+    assert np.all(np.abs(have_sim - want_sim) <= (1e-6 if space == "angulardist" else res))   # (acosf adds its own ulps)

@@ -191,19 +191,84 @@ def test_full_size_c3_1M_gpu_build_recall_and_self_queries():
     idx.close()
 
 
-def test_algotype_old_is_served_by_v1merge_with_equivalent_results():
-    """algoType=old (SearchOld, hnsw_distfunc_opt.cc:46-150: priority-queue best-first) is answered by the
-    V1Merge kernel.  Both explore with the same ef-bounded frontier rule, so on the same graph the result
-    sets coincide except for rare boundary cases; quantified here against the oracle's SearchOld."""
-    n, D, nq, k = 20000, 64, 256, 10
+def test_algotype_old_equals_reference_searchold(golden, tmp_path):
+    """algoType=old runs the SearchOld kernel (hnsw_distfunc_opt.cc:46-150: candidate heap + closest queue +
+    KNNQueue): on the reference's own graph file the results equal the reference's SearchOld outputs (golden)."""
+    p = str(tmp_path / "ref.idx")
+    golden["hnsw_l2_index_file"].tofile(p)
+    idx = nz.Index.load(p, load_data=False)
+    qs = golden["f32_D128_queries"]
+    for ef in (5, 20, 200):          # ef=5 < k=10: the result queue outlives the closest queue (differs from V1Merge)
+        idx.setQueryTimeParams(efSearch=ef, algoType="old")
+        ids, ds, cnt = idx.knnQueryBatch(qs, 10)
+        want_i, want_d = golden[f"hnsw_l2_ef{ef}_old_ids"], golden[f"hnsw_l2_ef{ef}_old_dists"]
+        valid = want_i >= 0
+        np.testing.assert_array_equal(ids[valid], want_i[valid])
+        assert close_rel(ds[valid], want_d[valid])
+        np.testing.assert_array_equal(cnt, valid.sum(1))
+    idx.close()
+
+
+@pytest.mark.parametrize("space,D", [("l2", 128), ("cosinesimil", 100), ("negdotprod", 21), ("l1", 21)])
+def test_golden_build_then_search_old(golden, space, D):
+    idx = make_index(space, "hnsw", golden[f"f32_D{D}_base"], M=8, efConstruction=50, indexThreadQty=1)
+    qs = golden[f"f32_D{D}_queries"]
+    for ef in (5, 20, 200):
+        idx.setQueryTimeParams(efSearch=ef, algoType="old")
+        ids, ds, cnt = idx.knnQueryBatch(qs, 10)
+        want_i, want_d = golden[f"hnsw_{space}_ef{ef}_old_ids"], golden[f"hnsw_{space}_ef{ef}_old_dists"]
+        valid = want_i >= 0
+        assert close_rel(ds[valid], want_d[valid])
+        assert ids_match_modulo_ties(ids, ds, want_i, want_d) or (ids[valid] == want_i[valid]).mean() >= 0.999
+    idx.close()
+
+
+def test_searchold_oracle_parity_with_counters_and_no_limits():
+    """SearchOld against the oracle's SearchOld on the same graph: ids, distances and the work counters; ef beyond
+    the V1Merge kernel's 1024 (HBM-resident candidate heap), k > ef, and the hybrid dispatch at ef >= 1000
+    (Hnsw::Search, hnsw.cc:717-746)."""
+    n, D, nq = 20000, 64, 128
     X, Q = refio.s_lowrank(n, D, 81), refio.s_lowrank(nq, D, 82)
     idx = make_index("l2", "hnsw", X, M=16, efConstruction=100, indexThreadQty=1)
     g = orc.HnswGraph.build("l2", X, 16, 100)
-    for ef in (20, 100):
+    for ef, k, algo in ((20, 10, "old"), (100, 10, "old"), (10, 50, "old"), (1500, 10, "old"), (1000, 10, "hybrid"),
+                        (3000, 2500, "hybrid")):
+        idx.setQueryTimeParams(efSearch=ef, algoType=algo)
+        ids, ds, cnt = idx.knnQueryBatch(Q, k)
+        opos, odist, ocnt, ondc, ohops = g.search(Q, k, ef, algo="old")
+        np.testing.assert_array_equal(cnt, ocnt)
+        assert (ids == opos).mean() >= 0.999, (ef, k, (ids == opos).mean())
+        valid = opos >= 0                                    # k > found: both sides pad with -1 / +inf
+        assert close_rel(ds[valid], odist[valid]) and np.isinf(ds[~valid]).all()
+        ndc, hops, _ = (x.astype(np.int64) for x in idx.read_counters(nq))
+        assert np.mean(ndc == ondc) >= 0.98 and abs(ndc.mean() / ondc.mean() - 1) < 0.01, (ef, k)
+        assert np.mean(hops == ohops) >= 0.98, (ef, k)
+    # hybrid below 1000 stays on V1Merge: counters of the V1Merge oracle
+    idx.setQueryTimeParams(efSearch=999, algoType="hybrid")
+    ids, ds, cnt = idx.knnQueryBatch(Q, 10)
+    opos, odist, _, ondc, _ = g.search(Q, 10, 999, algo="v1merge")
+    assert (ids == opos).mean() >= 0.999
+    idx.close()
+
+
+def test_searchold_exact_under_heavy_ties_u8():
+    """Integer distances on a 3-symbol alphabet + duplicated rows: equal keys everywhere.  The candidate queue's pop
+    order among equal keys is the binary heap's (libstdc++ push_heap/pop_heap), reproduced move for move, so ids
+    AND counters equal the oracle exactly."""
+    rng = np.random.default_rng(7)
+    U = (rng.integers(0, 3, (6000, 128)) * 40).astype(np.uint8)
+    U[500:560] = U[3]
+    UQ = (rng.integers(0, 3, (48, 128)) * 40).astype(np.uint8)
+    UQ[0] = U[3]
+    idx = make_index("l2sqr_sift", "hnsw", U, M=8, efConstruction=60, indexThreadQty=1)
+    g = orc.HnswGraph.build("l2sqr_sift", U, 8, 60)
+    for ef, k in ((30, 10), (200, 100), (1200, 20)):
         idx.setQueryTimeParams(efSearch=ef, algoType="old")
-        ids, ds, _ = idx.knnQueryBatch(Q, k)
-        opos, odist, _, _, _ = g.search(Q, k, ef, algo="old")
-        agree = np.mean([len(set(a) & set(b)) / k for a, b in zip(ids.tolist(), opos.tolist())])
-        assert agree >= 0.995, (ef, agree)
-        assert close_rel(np.sort(ds, axis=1)[:, 0], np.sort(odist, axis=1)[:, 0])
+        ids, ds, cnt = idx.knnQueryBatch(UQ, k)
+        opos, odist, ocnt, ondc, ohops = g.search(UQ, k, ef, algo="old")
+        np.testing.assert_array_equal(ds, odist)
+        np.testing.assert_array_equal(ids, opos)
+        ndc, hops, _ = (x.astype(np.int64) for x in idx.read_counters(len(UQ)))
+        np.testing.assert_array_equal(ndc, ondc)
+        np.testing.assert_array_equal(hops, ohops)
     idx.close()

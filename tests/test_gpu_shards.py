@@ -1,0 +1,79 @@
+"""-m gpu: row shards behind ONE index handle (index parameter gpu_shards, SURVEY.md 8e / VERDICT r01 #7).
+On a one-GPU box the shards share the device; the code path (per-shard engines, streams, peer copies, merge by
+(distance, global position), id map) is the one an 8-GPU node runs.  The exact scan must reproduce the unsharded
+index bit for bit."""
+import numpy as np
+import pytest
+
+import nmslib_zig_amd as nz
+from tests import refio
+from tests.gpuutil import make_index
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("space,shards", [("l2", 2), ("l2", 3), ("cosinesimil", 2), ("l2sqr_sift", 2), ("l1", 2)])
+def test_sharded_scan_equals_unsharded_bit_for_bit(space, shards):
+    n, nq = 30011, 97
+    if space == "l2sqr_sift":
+        rng = np.random.default_rng(3)
+        X = (rng.integers(0, 3, (n, 128)) * 60).astype(np.uint8)            # heavy ties: positions decide
+        Q = (rng.integers(0, 3, (nq, 128)) * 60).astype(np.uint8)
+        k = 50
+    else:
+        X, Q = refio.s_lowrank(n, 96, 5), refio.s_lowrank(nq, 96, 6)
+        X[2000:2040] = X[17]                                                # planted duplicates across a shard border
+        X[n // shards - 3:n // shards + 3] = X[17]
+        k = 10
+    ext = (np.random.default_rng(1).permutation(n).astype(np.int32) * 3 + 1)   # external ids unrelated to positions
+    one = make_index(space, "seq_search", X, ext, gpu_shards=1)
+    many = make_index(space, "seq_search", X, ext, gpu_shards=shards)
+    assert many.stats()["shards"] == shards and one.stats()["shards"] == 1
+    a = one.knnQueryBatch(Q, k)
+    b = many.knnQueryBatch(Q, k)
+    for x, y in zip(a, b):
+        np.testing.assert_array_equal(x, y)
+    # single query entry + range query
+    i1, d1 = many.knnQuery(Q[5], k)
+    np.testing.assert_array_equal(i1, a[0][5])
+    np.testing.assert_array_equal(d1, a[1][5])
+    r = float(a[1][3, k - 1])
+    ra, rb = one.rangeQueryFill(Q[3], r, 64), many.rangeQueryFill(Q[3], r, 64)
+    np.testing.assert_array_equal(ra[0], rb[0])
+    np.testing.assert_array_equal(ra[1], rb[1])
+    one.close()
+    many.close()
+
+
+def test_sharded_more_shards_than_useful_and_k_beyond_a_shard():
+    X, Q = refio.s_gauss(50, 16, 1), refio.s_gauss(7, 16, 2)
+    one = make_index("l2", "seq_search", X, gpu_shards=1)
+    many = make_index("l2", "seq_search", X, gpu_shards=4)                   # 12-13 rows per shard, k = 20
+    a, b = one.knnQueryBatch(Q, 20), many.knnQueryBatch(Q, 20)
+    for x, y in zip(a, b):
+        np.testing.assert_array_equal(x, y)
+    huge = make_index("l2", "seq_search", X[:3], gpu_shards=8)               # clamped to the number of rows
+    ids, ds, cnt = huge.knnQueryBatch(Q, 5)
+    assert (cnt == 3).all() and (ids[:, 3:] == -1).all()
+    for i in (one, many, huge):
+        i.close()
+
+
+def test_sharded_hnsw_recall_and_save_is_refused(tmp_path):
+    n, nq, k = 40000, 300, 10
+    X, Q = refio.s_lowrank(n, 64, 7), refio.s_lowrank(nq, 64, 8)
+    bf = make_index("l2", "seq_search", X)
+    gi, gd, _ = bf.knnQueryBatch(Q, k + 22)
+    bf.close()
+    rec = {}
+    for sh in (1, 2):
+        idx = make_index("l2", "hnsw", X, M=16, efConstruction=100, gpu_shards=sh)
+        idx.setQueryTimeParams(efSearch=64)
+        ids, ds, cnt = idx.knnQueryBatch(Q, k)
+        rec[sh] = refio.recall_nmslib(ids, gi, gd ** 2, k)
+        assert (cnt == k).all() and np.all(np.diff(ds, axis=1) >= 0)
+        if sh == 2:
+            with pytest.raises(nz.NmslibError):
+                idx.save(str(tmp_path / "sharded.idx"), save_data=False)
+        idx.close()
+    assert rec[2] >= rec[1] - 0.002, rec        # each shard returns its local top-k: never worse than one graph
