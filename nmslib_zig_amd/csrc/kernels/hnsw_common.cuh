@@ -162,4 +162,103 @@ __device__ __forceinline__ void frontier_distances(const HnswDeviceGraph& g, con
     }
 }
 
+// Split-phase form of frontier_distances for the software-pipelined search loop: issue() requests the first 128 floats
+// (u8: the whole row) of the first 32 rows and returns; finish() consumes them, fetches whatever is left (longer rows,
+// rows 32..m) and writes nd[0..m).  Same arithmetic, same order as frontier_distances (bit-identical results).
+template <int SPACE>
+struct FrontierLoads {
+    f32x4 bb[4][4];
+    i32x4 bu[4];
+    int ids[4];
+};
+
+template <int SPACE>
+__device__ __forceinline__ void frontier_issue(FrontierLoads<SPACE>& L, const HnswDeviceGraph& g, const int* nbr, int m,
+                                               int lane) {
+    const int g8 = lane >> 3, sub = lane & 7;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int idx = p * 8 + g8;
+        L.ids[p] = nbr[idx < m ? idx : m - 1];
+    }
+    if constexpr (DistTraits<SPACE>::kU8) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+            L.bu[p] = *reinterpret_cast<const i32x4*>(reinterpret_cast<const uint8_t*>(g.rows) + (size_t)L.ids[p] * 128 +
+                                                       sub * 16);
+    } else {
+        const float* rows = reinterpret_cast<const float*>(g.rows);
+        const int dlast = g.ldv - 4;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int d = sub * 4 + 32 * it;
+            const int dc = d < dlast ? d : dlast;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) L.bb[it][p] = *reinterpret_cast<const f32x4*>(rows + (size_t)L.ids[p] * g.ldv + dc);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int SPACE>
+__device__ __forceinline__ void frontier_finish(FrontierLoads<SPACE>& L, const HnswDeviceGraph& g, const float* qv,
+                                                const uint8_t* qb, int qnorm, const int* nbr, float* nd, int m,
+                                                int lane) {
+    const int g8 = lane >> 3, sub = lane & 7;
+    if constexpr (DistTraits<SPACE>::kU8) {
+        const i32x4 qq = *reinterpret_cast<const i32x4*>(qb + sub * 16);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            int dsum = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dsum = __builtin_amdgcn_udot4(qq[j], L.bu[p][j], dsum, false);
+            const int dot = group8_sum_i(dsum);
+            const int idx = p * 8 + g8;
+            if (sub == 0 && idx < m) nd[idx] = (float)(g.row_norm[L.ids[p]] + qnorm - 2 * dot);
+        }
+    } else {
+        float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+        const float* rows = reinterpret_cast<const float*>(g.rows);
+        const int dlast = g.ldv - 4;
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        for (int d0 = sub * 4; d0 < g.ldv; d0 += 128) {
+            if (d0 != sub * 4) {  // chunks after the first: fetched here (rows longer than 128 floats)
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int d = d0 + 32 * it;
+                    const int dc = d < dlast ? d : dlast;
+#pragma unroll
+                    for (int p = 0; p < 4; ++p)
+                        L.bb[it][p] = *reinterpret_cast<const f32x4*>(rows + (size_t)L.ids[p] * g.ldv + dc);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int d = d0 + 32 * it;
+                const bool ok = d < g.ldv;
+                const int dc = d < dlast ? d : dlast;
+                f32x4 qq = *reinterpret_cast<const f32x4*>(qv + dc);
+                qq = ok ? qq : zero;
+#pragma unroll
+                for (int p = 0; p < 4; ++p) accum4<SPACE>(qq, ok ? L.bb[it][p] : zero, s0[p], s1[p], s2[p]);
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            float r0, r1 = 0.f, r2 = 0.f;
+            if constexpr (DistTraits<SPACE>::kMax) r0 = group8_max(s0[p]);
+            else r0 = group8_sum(s0[p]);
+            if constexpr (DistTraits<SPACE>::kThree) {
+                r1 = group8_sum(s1[p]);
+                r2 = group8_sum(s2[p]);
+            }
+            const int idx = p * 8 + g8;
+            if (sub == 0 && idx < m) nd[idx] = finish_dist<SPACE>(r0, r1, r2);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (m > 32) frontier_distances<SPACE>(g, qv, qb, qnorm, nbr + 32, nd + 32, m - 32, lane);
+}
+
 }  // namespace gfxknn

@@ -211,6 +211,13 @@ __device__ __forceinline__ void hnsw_search_body(const HnswArgs& a, char* smem, 
     };
     int cursor = 0;
     int pre_node = -1, pre_v = 0, pre2_node = -1, pre2_v = 0;
+    float pre_key = INFINITY;
+    bool pre_ok = false;            // pre_node is the first unused item of the array, at a position below ef
+    // Software pipeline across expansions: when the NEXT node to expand is already certain before the accepted items of
+    // this expansion are merged in (it is the array's next unused item and every accepted key is larger), its visited
+    // filter runs and its row gather is issued first, and the merge executes while those rows are in flight.
+    int pipe_node = -1, pipe_m = 0;
+    FrontierLoads<SPACE> fl;
     long long pc[6] = {0, 0, 0, 0, 0, 0};
     long long pt = a.prof ? (long long)__builtin_readcyclecounter() : 0;
     auto lap = [&](int ph) __attribute__((always_inline)) {
@@ -238,62 +245,75 @@ __device__ __forceinline__ void hnsw_search_body(const HnswArgs& a, char* smem, 
         const float topKey = keys[n - 1];
         const int size0 = n;
 
-        // adjacency of c: [count][ids...]
-        int v;
-        if (c == pre_node) v = pre_v;
-        else if (c == pre2_node) v = pre2_v;
-        else v = load_adj(c);
-        // Adjacency of the NEXT expansion, requested early so that its latency (a random HBM read under
-        // load: ~2 us) hides behind this expansion's gather and inserts.  Two guesses: (A) now, the next
-        // unused item of the array -- right unless this expansion finds something closer; (B) after the
-        // distances, the best newly accepted item when it is closer than (A).
-        const int cntn = __builtin_amdgcn_readfirstlane(v);
-        lap(1);
-        const int nb = __shfl(v, lane + 1, 64);   // neighbours 0..62 (list words 1..63)
-        bool isn = false;
-        if (lane < cntn && (!WIDE || lane < 63)) isn = visit((uint32_t)nb);
-        const u64 nmask = __ballot(isn);
-        int m = __popcll(nmask);
-        if (isn) nbr[__popcll(nmask & ((1ull << lane) - 1ull))] = nb;
-        if (WIDE && cntn > 63) {
-            // wide level-0 lists (maxM0 > 62, i.e. M >= 32): neighbours 63.. are list words 64.., read on demand
-            int nb2 = 0;
-            if (64 + lane <= g.maxM0) nb2 = g.links0[(size_t)c * (g.maxM0 + 1) + 64 + lane];
-            bool isn2 = false;
-            if (63 + lane < cntn) isn2 = visit((uint32_t)nb2);
-            const u64 nmask2 = __ballot(isn2);
-            if (isn2) nbr[m + __popcll(nmask2 & ((1ull << lane) - 1ull))] = nb2;
-            m += __popcll(nmask2);
-        }
-        nvisited += m;
-        if (!BITSET && nvisited > (a.table_size - (a.table_size >> 3))) {
-            overflow = true;  // visited table nearly full: give up, the host re-runs with a bitset
-            break;
-        }
-        __builtin_amdgcn_wave_barrier();
-        lap(2);
-        // (issued only now: v had to be waited for first, and vmcnt retires in order -- a younger
-        //  outstanding load in front of that wait would put its whole latency into it)
-        float pre_key = INFINITY;
-        {
-            int fu2 = n;
-            for (int base = cursor; base < n && fu2 == n; base += 64) {
-                const int i = base + lane;
-                const u64 mk = __ballot(i < n && idu[i] >= 0);
-                if (mk) fu2 = base + (__ffsll((long long)mk) - 1);
+        int m;
+        if (c == pipe_node) {
+            // visited filter done and rows requested during the previous expansion; the guess for the expansion after
+            // this one was made there too
+            m = pipe_m;
+            pipe_node = -1;
+            lap(1);
+            lap(2);
+        } else {
+            // adjacency of c: [count][ids...]
+            int v;
+            if (c == pre_node) v = pre_v;
+            else if (c == pre2_node) v = pre2_v;
+            else v = load_adj(c);
+            // Adjacency of the NEXT expansion, requested early so that its latency (a random HBM read under
+            // load: ~2 us) hides behind this expansion's gather and inserts.  Two guesses: (A) now, the next
+            // unused item of the array -- right unless this expansion finds something closer; (B) after the
+            // distances, the best newly accepted item when it is closer than (A).
+            const int cntn = __builtin_amdgcn_readfirstlane(v);
+            lap(1);
+            const int nb = __shfl(v, lane + 1, 64);   // neighbours 0..62 (list words 1..63)
+            bool isn = false;
+            if (lane < cntn && (!WIDE || lane < 63)) isn = visit((uint32_t)nb);
+            const u64 nmask = __ballot(isn);
+            m = __popcll(nmask);
+            if (isn) nbr[__popcll(nmask & ((1ull << lane) - 1ull))] = nb;
+            if (WIDE && cntn > 63) {
+                // wide level-0 lists (maxM0 > 62, i.e. M >= 32): neighbours 63.. are list words 64.., read on demand
+                int nb2 = 0;
+                if (64 + lane <= g.maxM0) nb2 = g.links0[(size_t)c * (g.maxM0 + 1) + 64 + lane];
+                bool isn2 = false;
+                if (63 + lane < cntn) isn2 = visit((uint32_t)nb2);
+                const u64 nmask2 = __ballot(isn2);
+                if (isn2) nbr[m + __popcll(nmask2 & ((1ull << lane) - 1ull))] = nb2;
+                m += __popcll(nmask2);
             }
-            if (fu2 < lim) {
-                pre_node = idu[fu2] & 0x7FFFFFFF;
-                pre_key = keys[fu2];
-                pre_v = load_adj(pre_node);
-            } else {
-                pre_node = -1;
+            nvisited += m;
+            if (!BITSET && nvisited > (a.table_size - (a.table_size >> 3))) {
+                overflow = true;  // visited table nearly full: give up, the bitset variant re-runs the query
+                break;
             }
-            pre2_node = -1;
+            __builtin_amdgcn_wave_barrier();
+            lap(2);
+            // (issued only now: v had to be waited for first, and vmcnt retires in order -- a younger
+            //  outstanding load in front of that wait would put its whole latency into it)
+            {
+                int fu2 = n;
+                for (int base = cursor; base < n && fu2 == n; base += 64) {
+                    const int i = base + lane;
+                    const u64 mk = __ballot(i < n && idu[i] >= 0);
+                    if (mk) fu2 = base + (__ffsll((long long)mk) - 1);
+                }
+                if (fu2 < lim) {
+                    pre_node = idu[fu2] & 0x7FFFFFFF;
+                    pre_key = keys[fu2];
+                    pre_v = load_adj(pre_node);
+                    pre_ok = true;
+                } else {
+                    pre_node = -1;
+                    pre_key = INFINITY;
+                    pre_ok = false;
+                }
+                pre2_node = -1;
+            }
+            if (m > 0) frontier_issue<SPACE>(fl, g, nbr, m, lane);
         }
         if (m == 0) continue;
         ndc += m;
-        frontier_distances<SPACE>(g, qv, qb, qnorm, nbr, nd, m, lane);
+        frontier_finish<SPACE>(fl, g, qv, qb, qnorm, nbr, nd, m, lane);
         lap(3);
 
         // (more than 64 new rows only with wide lists: rounds of 64; without equal keys the final array does
@@ -330,6 +350,59 @@ __device__ __forceinline__ void hnsw_search_body(const HnswArgs& a, char* smem, 
             if (sk[0] <= pre_key) {  // guess (B)
                 pre2_node = si[0];
                 pre2_v = load_adj(pre2_node);
+            } else if (!WIDE && pre_ok) {
+                // Every accepted key is larger than the key of the array's next unused item: that item (pre_node,
+                // adjacency already here) IS the next expansion, whatever the merge below does to the positions
+                // behind it.  Run its visited filter now and request its rows; the merge overlaps the gather.
+                const int cntp = __builtin_amdgcn_readfirstlane(pre_v);
+                const int nbp = __shfl(pre_v, lane + 1, 64);
+                bool isp = false;
+                if (lane < cntp) isp = visit((uint32_t)nbp);
+                const u64 pmask = __ballot(isp);
+                const int mp = __popcll(pmask);
+                __builtin_amdgcn_wave_barrier();  // (nbr/nd of this expansion were consumed into registers above)
+                if (isp) nbr[__popcll(pmask & ((1ull << lane) - 1ull))] = nbp;
+                nvisited += mp;
+                if (!BITSET && nvisited > (a.table_size - (a.table_size >> 3))) {
+                    overflow = true;
+                    break;
+                }
+                __builtin_amdgcn_wave_barrier();
+                pipe_node = pre_node;
+                pipe_m = mp;
+                // guess for the expansion after that: the second unused item of the array, or the best accepted
+                // key if that is closer (then its position is only known after the merge: no pipelining on it)
+                int second = n;
+                {
+                    int seen = 0;
+                    for (int base = cursor; base < n && second == n; base += 64) {
+                        const int i = base + lane;
+                        u64 mk = __ballot(i < n && idu[i] >= 0);
+                        if (seen == 0 && mk) {
+                            mk &= mk - 1;
+                            seen = 1;
+                        }
+                        if (mk) second = base + (__ffsll((long long)mk) - 1);
+                    }
+                }
+                const float k2 = second < n ? keys[second] : INFINITY;
+                if (second < n && second < a.ef && k2 < sk[0]) {
+                    pre_node = idu[second] & 0x7FFFFFFF;
+                    pre_key = k2;
+                    pre_ok = true;
+                    pre_v = load_adj(pre_node);
+                } else if (sk[0] < k2) {
+                    pre_node = si[0];
+                    pre_key = sk[0];
+                    pre_ok = false;
+                    pre_v = load_adj(pre_node);
+                } else {
+                    pre_node = -1;
+                    pre_key = INFINITY;
+                    pre_ok = false;
+                }
+                pre2_node = -1;
+                if (mp > 0) frontier_issue<SPACE>(fl, g, nbr, mp, lane);
             }
             lap(4);
             // All accepted items at once when no two keys involved are equal (the normal case): the result of
@@ -470,6 +543,7 @@ __device__ __forceinline__ void hnsw_search_body(const HnswArgs& a, char* smem, 
                 }
             }
         }
+        if (overflow) break;  // (set inside the round loop by the pipelined visited filter)
         lap(5);
     }
     if (a.prof && lane == 0) {
