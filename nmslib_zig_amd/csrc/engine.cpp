@@ -232,7 +232,7 @@ size_t Engine::hbm_bytes() const {
     size_t sh = 0;
     for (const auto& c : shards_) sh += c->hbm_bytes();
     return sh + d_rows_.bytes() + d_rows_i8_.bytes() + d_aux_.bytes() + d_ids_.bytes() + d_links0_.bytes() + d_up_off_.bytes() +
-           d_up_links_.bytes() + d_rownorm_.bytes() + d_rows_sel_.bytes();
+           d_up_links_.bytes() + d_rownorm_.bytes() + d_rows_sel_.bytes() + d_auxh_.bytes();
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -698,8 +698,9 @@ void Engine::finalize() {
             const size_t n_pad = (size_t)bf_u8_rows_padded((int)n);
             d_aux_.ensure(n_pad * 4);
             d_rows_i8_.ensure(n_pad * 128);
+            d_auxh_.ensure(n_pad * 4);
             hip_check(launch_prepare_u8(d_rows_.as<uint8_t>(), (int)n, d_rows_i8_.as<uint8_t>(), d_aux_.as<int32_t>(),
-                                        stream_),
+                                        d_auxh_.as<int32_t>(), stream_),
                       "prepare u8 rows");
         } else {
             d_aux_.ensure(std::max<size_t>(n, 1) * 4);
@@ -927,6 +928,36 @@ void Engine::knn_brute(const void* d_queries, size_t nq, size_t k, int32_t* d_id
         throw EngineError(Err::QueryTooLarge, "k larger than " + std::to_string(BF_MAX_K) +
                                                   " is not supported by the brute-force GPU kernels");
     const int dim_eff = d_n_ ? (int)dim_ : 1;
+    if (is_u8()) {
+        // large batches: thresholds fixed by a sample pass, then one streaming scan (bf_kernels.hip, bf_scan_u8_kernel)
+        const BfU8Fast f = bf_u8_fast_plan((int)d_n_, (int)nq, (int)k);
+        if (f.use) {
+            ws_qpad_.ensure((size_t)f.qpad * 128);
+            ws_cand_.ensure(bf_cand_elems(f.fallback) * 8);
+            ws_cnt_.ensure(bf_cnt_elems(f.fallback) * 4);
+            ws_u8_cand_.ensure(bf_u8_top8_elems(f) * 4);
+            ws_u8_thr_.ensure((size_t)f.qpad * 4 + (size_t)f.nqt * 4 + 64);
+            ws_u8_list_.ensure(bf_u8_list_elems(f) * 4);
+            ws_u8_listcnt_.ensure(bf_u8_listcnt_elems(f) * 4);
+            int* thr = ws_u8_thr_.as<int>();
+            int* tile_fail = thr + f.qpad;
+            hip_check(launch_pad_rows(d_queries, (int)nq, 128, ws_qpad_.ptr(), f.qpad, 128, 1, stream), "pad queries");
+            hipEvent_t eb = nullptr, ee = nullptr;
+            if (prof_ && prof_events_.size() < 65536) {
+                hip_check(hipEventCreate(&eb), "hipEventCreate");
+                hip_check(hipEventCreate(&ee), "hipEventCreate");
+                prof_events_.emplace_back(eb, ee);
+            }
+            hip_check(launch_bf_u8_fast(f, (int)d_n_, (int)nq, (int)k, d_rows_.as<uint8_t>(), d_rows_i8_.as<uint8_t>(),
+                                        d_aux_.as<int32_t>(), d_auxh_.as<int32_t>(), ws_qpad_.as<uint8_t>(),
+                                        ws_u8_cand_.as<int>(),
+                                        ws_cand_.as<unsigned long long>(), ws_cnt_.as<int>(), thr,
+                                        ws_u8_list_.as<uint32_t>(), ws_u8_listcnt_.as<int>(), tile_fail,
+                                        d_ids_.as<int32_t>(), d_ids, d_dists, d_cnt, eb, ee, stream),
+                      "bf_u8_fast");
+            return;
+        }
+    }
     BfPlan p = bf_make_plan((int)d_n_, dim_eff, (int)nq, (int)k, is_u8());
     if (d_n_ == 0) p.ldb = is_u8() ? 128 : f32_row_stride(dim_eff);
     const int elem = is_u8() ? 1 : 4;

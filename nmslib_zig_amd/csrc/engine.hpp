@@ -227,6 +227,8 @@ class Engine {
     int device_ = -1;
     hipStream_t stream_ = nullptr;
     DevBuf d_rows_, d_rows_i8_, d_aux_, d_ids_, d_links0_, d_up_off_, d_up_links_, d_rownorm_;
+    DevBuf d_auxh_;  // uint8 brute force: aux >> 1 (fast-path scan)
+    DevBuf ws_u8_cand_, ws_u8_cnt_, ws_u8_thr_, ws_u8_list_, ws_u8_listcnt_;
     DevBuf d_rows_sel_, d_mean_;  // brute-force L2 on un-centred data: selection copy (rows - column mean) and the mean
     bool centred_ = false;
     double mu_norm_ = 0;  // |column mean| (centred cosine scoring)

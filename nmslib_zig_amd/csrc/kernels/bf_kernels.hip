@@ -704,6 +704,9 @@ struct BfArgsU8 {
     int xj, xm;
     int n, nqt, nsplit, rows_per_split, kprime, cap;
     int dbg;
+    int tile_stride;          // 1: every 64-row tile; S: only tiles 0, S, 2S, ... (sample pass of the fast path)
+    const int* tile_fail;     // fallback launch of the fast path: query tiles whose flag is 0 have nothing to do
+    int fail_group;           // ... flags are kept per group of this many 128-query tiles
 };
 
 // Same selection machinery as the f32 kernel (block-max prefilter, pending keys, per-lane top-8,
@@ -728,6 +731,7 @@ __global__ __launch_bounds__(256, 2) void bf_select_u8_kernel(BfArgsU8 a) {
     const int qt = rest % a.nqt;
     const int split = (rest / a.nqt) * 8 + xcd;
     if (split >= a.nsplit) return;
+    if (a.tile_fail && a.tile_fail[qt / a.fail_group] == 0) return;
 
     constexpr int kRing = 6, kAuxRing = 8, kTileBytes = BF_BN * 128;
     constexpr int kThr0 = -(1 << 29);     // below every real score (|score| < 2^25); pad rows score ~ -2^30
@@ -742,15 +746,20 @@ __global__ __launch_bounds__(256, 2) void bf_select_u8_kernel(BfArgsU8 a) {
     u64* wave_cand = a.cand + ((size_t)(qt * BF_TQ + wave * 32) * a.nsplit + split) * a.cap;
     const size_t qstride = (size_t)a.nsplit * a.cap;
 
-    const int r_begin = split * a.rows_per_split;
-    const int r_end = min(a.n, r_begin + a.rows_per_split);
-    const int nstages = r_end > r_begin ? (r_end - r_begin + BF_BN - 1) / BF_BN : 0;
+    // stage j of this split = sample tile (split * tps + j) = rows [(split * tps + j) * tile_stride * 64, +64)
+    const int tstr = a.tile_stride;
+    const int tps = a.rows_per_split / BF_BN;
+    const int tiles_all = (a.n + BF_BN - 1) / BF_BN;
+    const int stiles_all = (tiles_all + tstr - 1) / tstr;
+    const int nstages = max(0, min(tps, stiles_all - split * tps));
+    const int r_begin = split * tps * tstr * BF_BN;
+    const int stage_rows = tstr * BF_BN;  // row distance between consecutive stages
 
     // one tile = 8 DMA pieces of 1 KiB (8 rows) + 64 aux words: each wave issues 2 pieces + 16 aux words
     const int dma_row = lane >> 3;                    // row inside a piece
     auto issue_tile = [&](int stage) __attribute__((always_inline)) {
         const int slot = stage % kRing;
-        const int row0 = r_begin + stage * BF_BN;
+        const int row0 = r_begin + stage * stage_rows;
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj) {
             const int j = 2 * wave + jj;
@@ -819,7 +828,7 @@ __global__ __launch_bounds__(256, 2) void bf_select_u8_kernel(BfArgsU8 a) {
     };
     auto check_block = [&](const i32x16& acc, int blk, int stage) __attribute__((always_inline)) {
         const int* ax = auxr + (stage % kAuxRing) * BF_BN + blk * 32 + 4 * h;
-        const int row0 = r_begin + stage * BF_BN + blk * 32;
+        const int row0 = r_begin + stage * stage_rows + blk * 32;
         int sc[16];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -914,6 +923,330 @@ __global__ __launch_bounds__(256, 2) void bf_select_u8_kernel(BfArgsU8 a) {
 }
 
 // ---------------------------------------------------------------------------------------
+// uint8 fast path (large batches): the selection threshold of every query is FIXED before the rows are streamed.
+//   1. sample pass   - bf_select_u8_kernel over every 8th 64-row tile with k' = r: the r-th best score of the sample
+//                      (bf_u8_threshold_kernel) is, with overwhelming probability, below the k-th best score of the
+//                      whole base while only ~r*8 rows reach it;
+//   2. scan          - bf_scan_u8_kernel: 128*QG queries per workgroup (QG x 32 per wave: the L2 -> LDS stream of the
+//                      rows, which bounds the adaptive kernel at 128 queries per workgroup, shrinks QG-fold), the
+//                      accumulators start from aux >> 1 (read from LDS straight into the MFMA registers) so that
+//                      acc = (score - (aux & 1)) / 2 needs no arithmetic; epilogue = one max tree + one compare per
+//                      32 x 64 block; rows that reach the threshold append their POSITION to the lane's own list;
+//   3. re-rank       - bf_rerank_u8_list_kernel: exact integer distances of the listed rows, (distance, position)
+//                      order, top k.  It also VERIFIES the bet: a query whose lists overflowed or hold fewer than k
+//                      rows flags its query-tile group;
+//   4. fallback      - flagged groups are redone by the adaptive kernel + bf_rerank_kernel (launched always; their
+//                      workgroups leave at once when the flag is clear).  The result is exact either way.
+// ---------------------------------------------------------------------------------------
+struct BfScanArgs {
+    const uint8_t* base_i8;   // [n_pad][128]
+    const int32_t* auxh;      // [n_pad] aux >> 1 (pad rows: -2^29)
+    const uint8_t* queries;   // [qpad][128]
+    const int* thr;           // [qpad] pass <=> dot' + auxh >= thr
+    uint32_t* list;           // [qpad][nsplit][2][caph] row positions
+    int* list_cnt;            // [qpad][nsplit][2]
+    int n, nqt, nsplit, tps, caph;
+    int tile_stride;          // SAMPLE: every tile_stride-th tile
+    int* top8;                // SAMPLE: [qpad][nsplit][2][8] best (score >> 1) values each lane saw, descending
+};
+
+// SAMPLE = the sample pass: no thresholds yet; every lane keeps the 8 best values it sees (sorted insertion network in
+// registers, entered only when a value beats the lane's 8th best) and writes them out at the end.
+template <int QG, bool SAMPLE>
+__global__ __launch_bounds__(256, 2) void bf_scan_u8_kernel(BfScanArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, l31 = lane & 31;
+    const int b = blockIdx.x;
+    const int xcd = b & 7, rest = b >> 3;
+    const int qt = rest % a.nqt;
+    const int split = (rest / a.nqt) * 8 + xcd;
+    if (split >= a.nsplit) return;
+
+    constexpr int kRing = 6, kAuxRing = 8, kTileBytes = BF_BN * 128;
+    char* ring = smem;
+    int* auxr = reinterpret_cast<int*>(ring + kRing * kTileBytes);
+
+    const int tstr = SAMPLE ? a.tile_stride : 1;
+    const int tiles_all = (a.n + BF_BN - 1) / BF_BN;
+    const int stiles_all = (tiles_all + tstr - 1) / tstr;
+    const int nstages = max(0, min(a.tps, stiles_all - split * a.tps));
+    const int r_begin = split * a.tps * tstr * BF_BN;
+    const int stage_rows = tstr * BF_BN;
+
+    const int dma_row = lane >> 3;
+    auto issue_tile = [&](int stage) __attribute__((always_inline)) {
+        const int slot = stage % kRing;
+        const int row0 = r_begin + stage * stage_rows;
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const int j = 2 * wave + jj;
+            const int row = 8 * j + dma_row;
+            const int c = (lane & 7) ^ ((row >> 1) & 7);
+            const uint8_t* src = a.base_i8 + (size_t)(row0 + row) * 128 + c * 16;
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(ring + slot * kTileBytes + j * 1024), 16, 0, 0);
+        }
+        if (lane < 16)
+            __builtin_amdgcn_global_load_lds((gptr_t)(a.auxh + row0 + 16 * wave + lane),
+                                             (lptr_t)(auxr + (stage % kAuxRing) * BF_BN + 16 * wave), 4, 0, 0);
+    };
+
+    // this lane's QG queries, their thresholds, their lists (each lane owns the rows of its half h: no atomics)
+    i32x4 bq[QG][4];
+    int thr[QG], cnt[QG];
+    uint32_t* lp[QG];
+    int t8[SAMPLE ? QG : 1][8];
+#pragma unroll
+    for (int g = 0; g < QG; ++g) {
+        const int qidx = (qt * 4 + wave) * (32 * QG) + g * 32 + l31;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            i32x4 v = *reinterpret_cast<const i32x4*>(a.queries + (size_t)qidx * 128 + 32 * ks + 16 * h);
+            bq[g][ks] = v ^ (int)0x80808080;
+        }
+        cnt[g] = 0;
+        if constexpr (SAMPLE) {
+            thr[g] = -(1 << 28);  // above the pad rows' -2^29: they never enter the lists
+            lp[g] = nullptr;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) t8[g][i] = -(1 << 28);
+        } else {
+            thr[g] = a.thr[qidx];
+            lp[g] = a.list + (((size_t)qidx * a.nsplit + split) * 2 + h) * a.caph;
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): retire the query loads before any DMA is counted
+
+    for (int t = 0; t < kRing - 1 && t < nstages; ++t) issue_tile(t);
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+
+    const int sw = (l31 >> 1) & 7;
+    // rows of one finished 32 x 64 block pair that reach the threshold: position appended to the lane's list
+    auto examine = [&](const i32x16& c0, const i32x16& c1, int g, int row0) __attribute__((always_inline)) {
+        int m0 = max(max(c0[0], c0[1]), c0[2]);
+#pragma unroll
+        for (int i = 3; i + 1 < 16; i += 2) m0 = max(max(m0, c0[i]), c0[i + 1]);
+        m0 = max(m0, c0[15]);
+        int m1 = max(max(c1[0], c1[1]), c1[2]);
+#pragma unroll
+        for (int i = 3; i + 1 < 16; i += 2) m1 = max(max(m1, c1[i]), c1[i + 1]);
+        m1 = max(m1, c1[15]);
+        const int tg = thr[g];
+        if constexpr (SAMPLE) {
+            if (__any(max(m0, m1) > tg)) {
+                auto ins = [&](int v) __attribute__((always_inline)) {
+                    if (v > t8[g][7]) {
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            const int hi = max(t8[g][i], v);
+                            v = min(t8[g][i], v);
+                            t8[g][i] = hi;
+                        }
+                    }
+                };
+                if (__any(m0 > tg)) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) ins(c0[i]);
+                }
+                if (__any(m1 > tg)) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) ins(c1[i]);
+                }
+                thr[g] = t8[g][7];
+            }
+        } else if (__any(max(m0, m1) >= tg)) {
+            if (__any(m0 >= tg)) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    if (c0[i] >= tg) {
+                        if (cnt[g] < a.caph) lp[g][cnt[g]] = (uint32_t)(row0 + acc_row(i, h));
+                        cnt[g]++;
+                    }
+                }
+            }
+            if (__any(m1 >= tg)) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    if (c1[i] >= tg) {
+                        if (cnt[g] < a.caph) lp[g][cnt[g]] = (uint32_t)(row0 + 32 + acc_row(i, h));
+                        cnt[g]++;
+                    }
+                }
+            }
+        }
+    };
+
+    for (int t = 0; t < nstages; ++t) {
+        const char* tp = ring + (t % kRing) * kTileBytes + l31 * 128;
+        const int* ax = auxr + (t % kAuxRing) * BF_BN + 4 * h;
+        const int row0 = r_begin + t * stage_rows;
+        i32x4 fa[4], fb[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int off = ((2 * ks + h) ^ sw) * 16;
+            fa[ks] = *reinterpret_cast<const i32x4*>(tp + off);
+            fb[ks] = *reinterpret_cast<const i32x4*>(tp + 32 * 128 + off);
+        }
+        // accumulators start from aux >> 1 of their rows: acc register 4j+i of half h = row 8j + 4h + i of the block
+        i32x16 init0, init1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const i32x4 v0 = *reinterpret_cast<const i32x4*>(ax + 8 * j);
+            const i32x4 v1 = *reinterpret_cast<const i32x4*>(ax + 32 + 8 * j);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                init0[4 * j + i] = v0[i];
+                init1[4 * j + i] = v1[i];
+            }
+        }
+        // the slot of tile t+5 held tile t-1: every wave passed the barrier that ended stage t-1 after its reads
+        if (t + kRing - 1 < nstages) issue_tile(t + kRing - 1);
+        i32x16 p0, p1;  // scores of the previous query group, examined under the MFMAs of the current one
+#pragma unroll
+        for (int g = 0; g < QG; ++g) {
+            i32x16 c0 = init0, c1 = init1;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                c0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[ks], bq[g][ks], c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(fb[ks], bq[g][ks], c1, 0, 0, 0);
+            }
+            if (g > 0) examine(p0, p1, g - 1, row0);
+            p0 = c0;
+            p1 = c1;
+        }
+        examine(p0, p1, QG - 1, row0);
+        // tile t+1 must have landed; tiles t+2 .. t+5 (3 DMA instructions each) may stay in flight
+        if (t + kRing - 1 < nstages) asm volatile("s_waitcnt vmcnt(12)\n\ts_barrier" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+#pragma unroll
+    for (int g = 0; g < QG; ++g) {
+        const int qidx = (qt * 4 + wave) * (32 * QG) + g * 32 + l31;
+        if constexpr (SAMPLE) {
+            int* o = a.top8 + (((size_t)qidx * a.nsplit + split) * 2 + h) * 8;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o[i] = t8[g][i];
+        } else {
+            a.list_cnt[((size_t)qidx * a.nsplit + split) * 2 + h] = cnt[g];
+        }
+    }
+}
+
+// r-th best value of the sample (union of the lanes' top-8 lists) -> scan threshold of each query; one wave per query.
+// Any value works as a threshold -- the re-rank verifies the outcome -- this one makes ~r * stride rows pass.
+__global__ __launch_bounds__(64) void bf_u8_threshold_kernel(const int* top8, int nlists, int r, int nq, int* thr) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    u64* keys = reinterpret_cast<u64*>(smem);
+    const int q = blockIdx.x, lane = threadIdx.x;
+    constexpr int kPassAll = -(1 << 28);  // below every real value, above the pad rows' -2^29
+    if (q >= nq) {                        // padding queries: nothing may pass
+        if (lane == 0) thr[q] = 0x7FFFFFFF;
+        return;
+    }
+    const int total = nlists * 8;
+    const int P = next_pow2(total < 2 ? 2 : total);
+    for (int i = lane; i < P; i += 64) keys[i] = i < total ? (u64)i32_ord(top8[(size_t)q * total + i]) : 0ull;
+    __builtin_amdgcn_wave_barrier();
+    wave_bitonic_u64(keys, P, lane, /*descending=*/true);
+    if (lane == 0) {
+        int t = kPassAll;
+        if (total >= r) t = max(kPassAll, ord_i32((uint32_t)keys[r - 1]));
+        thr[q] = t;
+    }
+}
+
+// exact distances of the listed rows, canonical (distance, position) order, top k; verification of the threshold bet
+struct RerankListArgs {
+    const uint8_t* base;      // original bytes [n][128]
+    const uint8_t* queries;   // [qpad][128]
+    const uint32_t* list;
+    const int* list_cnt;
+    const int32_t* ext_ids;
+    int32_t* out_ids;
+    float* out_dists;
+    int32_t* out_cnt;
+    int* tile_fail;           // [ceil(nq / fail_queries)]
+    int n, k, nsplit, caph, p2max, fail_queries;
+};
+
+__global__ __launch_bounds__(256) void bf_rerank_u8_list_kernel(RerankListArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    u64* keys = reinterpret_cast<u64*>(smem);              // [p2max]
+    int* offs = reinterpret_cast<int*>(keys + a.p2max);    // [2 * nsplit + 1]
+    __shared__ int s_over;
+    const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nl = 2 * a.nsplit;
+    if (tid == 0) {
+        int o = 0, over = 0;
+        for (int s = 0; s < nl; ++s) {
+            offs[s] = o;
+            const int c = a.list_cnt[(size_t)q * nl + s];
+            over |= c > a.caph;
+            o += c < a.caph ? c : a.caph;
+        }
+        offs[nl] = o;
+        s_over = over;
+    }
+    __syncthreads();
+    const int total = offs[nl];
+    const int need = a.k < a.n ? a.k : a.n;
+    if (s_over || total < need || total > a.p2max) {
+        // lists overflowed (ties, or an unlucky sample), or fewer than k rows reached the threshold: the adaptive
+        // kernel redoes this query's tile group
+        if (tid == 0) atomicOr(&a.tile_fail[q / a.fail_queries], 1);
+        return;
+    }
+    for (int idx = tid; idx < nl * a.caph; idx += blockDim.x) {
+        const int s = idx / a.caph, i = idx - s * a.caph;
+        if (i < offs[s + 1] - offs[s]) keys[offs[s] + i] = (u64)a.list[((size_t)q * nl + s) * a.caph + i];
+    }
+    __syncthreads();
+    const int P = next_pow2(total < 2 ? 2 : total);
+    // sum (a-b)^2 = a.a + b.b - 2 a.b on packed bytes (exact in int32; distcomp_l2sqr_sift.cc:41-50 gives the same
+    // integer).  8 lanes x 16 bytes per row, 8 rows per wave and pass, the row loads of a pass issued together.
+    const uint8_t* qq = a.queries + (size_t)q * 128;
+    const int sub = lane & 7, g8 = lane >> 3;
+    const i32x4 qv = *reinterpret_cast<const i32x4*>(qq + sub * 16);
+    int qsq = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) qsq = __builtin_amdgcn_udot4(qv[j], qv[j], qsq, false);
+    for (int j0 = wave * 8; j0 < total; j0 += 32) {
+        const int j = j0 + g8;
+        const uint32_t pos = (uint32_t)keys[j < total ? j : total - 1];
+        const i32x4 bv = *reinterpret_cast<const i32x4*>(a.base + (size_t)pos * 128 + sub * 16);
+        int bsq = 0, dot = 0;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            bsq = __builtin_amdgcn_udot4(bv[t], bv[t], bsq, false);
+            dot = __builtin_amdgcn_udot4(bv[t], qv[t], dot, false);
+        }
+        int d = qsq + bsq - 2 * dot;
+        d += __shfl_xor(d, 1, 64);
+        d += __shfl_xor(d, 2, 64);
+        d += __shfl_xor(d, 4, 64);
+        __builtin_amdgcn_wave_barrier();
+        if (sub == 0 && j < total) keys[j] = ((u64)i32_ord(d) << 32) | pos;
+    }
+    for (int i = total + tid; i < P; i += blockDim.x) keys[i] = ~0ull;
+    __syncthreads();
+    block_bitonic_u64_asc(keys, P, tid, blockDim.x);
+    const int found = total < a.k ? total : a.k;
+    for (int i = tid; i < a.k; i += blockDim.x) {
+        int32_t id = -1;
+        float d = INFINITY;
+        if (i < found) {
+            const u64 key = keys[i];
+            const uint32_t pos = (uint32_t)key;
+            id = a.ext_ids ? a.ext_ids[pos] : (int32_t)pos;
+            d = (float)ord_i32((uint32_t)(key >> 32));
+        }
+        a.out_ids[(size_t)q * a.k + i] = id;
+        a.out_dists[(size_t)q * a.k + i] = d;
+    }
+    if (tid == 0 && a.out_cnt) a.out_cnt[q] = found;
+}
+
+// ---------------------------------------------------------------------------------------
 // Re-rank: one workgroup per query.  Exact reference-formula distance of every survivor,
 // 64-bit keys (distance, position) sorted ascending, first k emitted.
 // ---------------------------------------------------------------------------------------
@@ -927,6 +1260,8 @@ struct RerankArgs {
     float* out_dists;
     int32_t* out_cnt;
     int space, dim, ldb, k, nsplit, cap, kprime, p2max;
+    const int* tile_fail;  // u8 fast path fallback: only queries of flagged groups are redone
+    int fail_queries;
 };
 
 __global__ __launch_bounds__(256) void bf_rerank_kernel(RerankArgs a) {
@@ -934,6 +1269,7 @@ __global__ __launch_bounds__(256) void bf_rerank_kernel(RerankArgs a) {
     u64* keys = reinterpret_cast<u64*>(smem);                      // [p2max]
     int* offs = reinterpret_cast<int*>(keys + a.p2max);            // [nsplit + 1]
     const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (a.tile_fail && a.tile_fail[q / a.fail_queries] == 0) return;
 
     if (tid == 0) {
         int o = 0;
@@ -1033,14 +1369,17 @@ __global__ void row_aux_f32_kernel(const float* base, int n, int ldb, int dim, i
 }
 
 // aux[row] = 256*sum(a) - sum(a^2), rows_i8[row] = a ^ 0x80; rows n..n_pad-1: zero bytes, aux = kPadAux
-__global__ void prepare_u8_kernel(const uint8_t* base, int n, int n_pad, uint8_t* rows_i8, int32_t* aux) {
+__global__ void prepare_u8_kernel(const uint8_t* base, int n, int n_pad, uint8_t* rows_i8, int32_t* aux, int32_t* auxh) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (row >= n_pad) return;
     uint16_t* dst = reinterpret_cast<uint16_t*>(rows_i8 + (size_t)row * 128);
     if (row >= n) {
         dst[lane] = 0;
-        if (lane == 0) aux[row] = -(1 << 30);
+        if (lane == 0) {
+            aux[row] = -(1 << 30);
+            if (auxh) auxh[row] = -(1 << 29);
+        }
         return;
     }
     const uint8_t* p = base + (size_t)row * 128;
@@ -1048,7 +1387,10 @@ __global__ void prepare_u8_kernel(const uint8_t* base, int n, int n_pad, uint8_t
     dst[lane] = (uint16_t)((x0 | (x1 << 8)) ^ 0x8080);
     const int sum = wave_sum_i(x0 + x1);
     const int sq = wave_sum_i(x0 * x0 + x1 * x1);
-    if (lane == 0) aux[row] = 256 * sum - sq;
+    if (lane == 0) {
+        aux[row] = 256 * sum - sq;
+        if (auxh) auxh[row] = (256 * sum - sq) >> 1;
+    }
 }
 
 __global__ void pad_rows_kernel(const uint8_t* src, int rows, int row_bytes, uint8_t* dst, int rows_pad,
@@ -1219,11 +1561,11 @@ static int host_next_pow2(int v) {
     return p;
 }
 
-BfPlan bf_make_plan(int n, int dim, int nq, int k, bool is_u8) {
+BfPlan bf_make_plan(int n, int dim, int nq, int k, bool is_u8, int qpad_multiple) {
     BfPlan p{};
     p.nq = nq;
-    p.nqt = (nq + BF_TQ - 1) / BF_TQ;
-    p.qpad = p.nqt * BF_TQ;
+    p.qpad = (nq + qpad_multiple - 1) / qpad_multiple * qpad_multiple;
+    p.nqt = p.qpad / BF_TQ;
     p.n = n;
     p.ldb = is_u8 ? 128 : f32_row_stride(dim);
     // float scores are ranked in the Q.B^T form, whose rounding differs from the reference's
@@ -1382,7 +1724,16 @@ hipError_t launch_bf_select_direct_f32(const BfPlan& p, int space, const float* 
 hipError_t launch_bf_select_u8(const BfPlan& p, const uint8_t* base_i8, const int32_t* aux,
                                const uint8_t* queries_padded, unsigned long long* cand, int* cand_cnt,
                                hipStream_t s) {
+    return launch_bf_select_u8_ex(p, base_i8, aux, queries_padded, cand, cand_cnt, 1, nullptr, 1, s);
+}
+
+hipError_t launch_bf_select_u8_ex(const BfPlan& p, const uint8_t* base_i8, const int32_t* aux,
+                                  const uint8_t* queries_padded, unsigned long long* cand, int* cand_cnt,
+                                  int tile_stride, const int* tile_fail, int fail_group, hipStream_t s) {
     BfArgsU8 a{};
+    a.tile_stride = tile_stride;
+    a.tile_fail = tile_fail;
+    a.fail_group = fail_group;
     a.base_i8 = base_i8;
     a.aux = aux;
     a.queries = queries_padded;
@@ -1414,7 +1765,18 @@ hipError_t launch_bf_rerank(const BfPlan& p, int space, int dim, int k, const vo
                             const void* queries_padded, const unsigned long long* cand,
                             const int* cand_cnt, const int32_t* ext_ids, int32_t* out_ids,
                             float* out_dists, int32_t* out_cnt, hipStream_t s) {
+    return launch_bf_rerank_ex(p, space, dim, k, base, queries_padded, cand, cand_cnt, ext_ids, out_ids, out_dists,
+                               out_cnt, nullptr, 1, s);
+}
+
+hipError_t launch_bf_rerank_ex(const BfPlan& p, int space, int dim, int k, const void* base,
+                               const void* queries_padded, const unsigned long long* cand,
+                               const int* cand_cnt, const int32_t* ext_ids, int32_t* out_ids,
+                               float* out_dists, int32_t* out_cnt, const int* tile_fail, int fail_queries,
+                               hipStream_t s) {
     RerankArgs a{};
+    a.tile_fail = tile_fail;
+    a.fail_queries = fail_queries;
     a.base = base;
     a.queries = queries_padded;
     a.cand = cand;
@@ -1438,15 +1800,152 @@ hipError_t launch_bf_rerank(const BfPlan& p, int space, int dim, int k, const vo
     return hipGetLastError();
 }
 
+// ---- uint8 fast path (see bf_scan_u8_kernel) ----------------------------------------------------------------
+BfU8Fast bf_u8_fast_plan(int n, int nq, int k) {
+    BfU8Fast f{};
+    f.use = (n >= 131072 && nq >= 512 && k <= 256);
+    if (const char* e = getenv("NMSLIB_GPU_U8_FAST")) f.use = f.use && atoi(e) != 0;
+    if (!f.use) return f;
+    f.qg = nq >= 2048 ? 4 : 2;
+    const int tq = BF_TQ * f.qg;
+    f.qpad = (nq + tq - 1) / tq * tq;
+    f.nqt = f.qpad / tq;
+    f.stride = 8;
+    // r-th best of a 1/stride sample: expected k/stride rows of the true top-k fall into the sample; r sits
+    // ~3 sigma above that (+ slack), so that fewer than k rows reaching the threshold is a ~1e-6 event per query
+    const double kf = (double)k / f.stride;
+    f.r = (int)(1.6 * kf + 3.0 * sqrt(kf) + 3.0 + 0.999);
+    const int tiles_all = (n + BF_BN - 1) / BF_BN;
+    int ns = (512 + f.nqt - 1) / f.nqt;
+    if (ns > tiles_all / 16) ns = tiles_all / 16;  // at least 16 stages per split
+    if (ns > 256) ns = 256;
+    ns = (ns + 7) / 8 * 8;
+    if (ns < 8) ns = 8;
+    f.nsplit = ns;
+    f.tps = (tiles_all + ns - 1) / ns;
+    const double mean_half = (double)f.r * f.stride / (2.0 * ns);
+    int caph = 8;
+    while (caph < 4.0 * mean_half + 8.0) caph <<= 1;
+    f.caph = caph;
+    f.p2max = host_next_pow2(2 * ns * caph);
+    f.lds_scan = 6 * BF_BN * 128 + 8 * BF_BN * 4 + 64;
+    f.lds_rerank = (size_t)f.p2max * 8 + (2 * (size_t)ns + 1) * 4 + 16;
+    // sample pass = the same streaming kernel over every stride-th tile, per-lane top-8 lists instead of thresholds
+    // (always with 2 query groups per wave: twice the workgroups of the scan for the same row splits -- the sample
+    //  has few stages per split, so it is split coarsely and parallelised over the queries instead)
+    const int stiles = (tiles_all + f.stride - 1) / f.stride;
+    const int s_nqt = f.qpad / (BF_TQ * 2);
+    int nss = (256 + s_nqt - 1) / s_nqt;
+    if (nss > stiles / 32) nss = stiles / 32;
+    if (nss > 64) nss = 64;
+    nss = (nss + 7) / 8 * 8;
+    if (nss < 8) nss = 8;
+    f.s_nsplit = nss;
+    f.s_tps = (stiles + nss - 1) / nss;
+    f.lds_thr = (size_t)host_next_pow2(nss * 2 * 8) * 8 + 16;
+    // fallback = the adaptive kernel over everything, same query padding
+    f.fallback = bf_make_plan(n, 128, nq, k, true, tq);
+    return f;
+}
+
+hipError_t launch_bf_u8_fast(const BfU8Fast& f, int n, int nq, int k, const uint8_t* base_u8, const uint8_t* base_i8,
+                             const int32_t* aux, const int32_t* auxh, const uint8_t* queries_padded,
+                             int* top8, unsigned long long* cand_fb, int* cnt_fb,
+                             int* thr, uint32_t* list, int* list_cnt, int* tile_fail, const int32_t* ext_ids,
+                             int32_t* out_ids, float* out_dists, int32_t* out_cnt, hipEvent_t scan_begin,
+                             hipEvent_t scan_end, hipStream_t s) {
+    hipError_t e;
+    auto scan = [&](const BfScanArgs& sa, int grid) -> hipError_t {
+        const void* fn = f.qg == 4 ? (const void*)bf_scan_u8_kernel<4, false> : (const void*)bf_scan_u8_kernel<2, false>;
+        hipError_t le = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)f.lds_scan);
+        if (le != hipSuccess) return le;
+        if (f.qg == 4) hipLaunchKernelGGL((bf_scan_u8_kernel<4, false>), dim3(grid), dim3(256), f.lds_scan, s, sa);
+        else hipLaunchKernelGGL((bf_scan_u8_kernel<2, false>), dim3(grid), dim3(256), f.lds_scan, s, sa);
+        return hipGetLastError();
+    };
+    // 1. sample pass + thresholds
+    BfScanArgs sa{};
+    sa.base_i8 = base_i8;
+    sa.auxh = auxh;
+    sa.queries = queries_padded;
+    sa.n = n;
+    const int s_nqt = f.qpad / (BF_TQ * 2);
+    sa.nqt = s_nqt;
+    sa.nsplit = f.s_nsplit;
+    sa.tps = f.s_tps;
+    sa.tile_stride = f.stride;
+    sa.top8 = top8;
+    {
+        hipError_t le = hipFuncSetAttribute(reinterpret_cast<const void*>(bf_scan_u8_kernel<2, true>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)f.lds_scan);
+        if (le != hipSuccess) return le;
+        hipLaunchKernelGGL((bf_scan_u8_kernel<2, true>), dim3(8 * s_nqt * (f.s_nsplit / 8)), dim3(256), f.lds_scan, s, sa);
+        e = hipGetLastError();
+    }
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(bf_u8_threshold_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)f.lds_thr);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(bf_u8_threshold_kernel, dim3(f.qpad), dim3(64), f.lds_thr, s, top8, 2 * f.s_nsplit, f.r, nq, thr);
+    e = hipMemsetAsync(tile_fail, 0, (size_t)f.nqt * 4, s);
+    if (e != hipSuccess) return e;
+    // 2. scan with fixed thresholds
+    BfScanArgs a{};
+    a.base_i8 = base_i8;
+    a.auxh = auxh;
+    a.queries = queries_padded;
+    a.thr = thr;
+    a.list = list;
+    a.list_cnt = list_cnt;
+    a.n = n;
+    a.nqt = f.nqt;
+    a.nsplit = f.nsplit;
+    a.tps = f.tps;
+    a.caph = f.caph;
+    a.tile_stride = 1;
+    if (scan_begin) (void)hipEventRecord(scan_begin, s);
+    e = scan(a, 8 * f.nqt * (f.nsplit / 8));
+    if (scan_end) (void)hipEventRecord(scan_end, s);
+    if (e != hipSuccess) return e;
+    // 3. exact re-rank of the listed rows + verification
+    RerankListArgs r{};
+    r.base = base_u8;
+    r.queries = queries_padded;
+    r.list = list;
+    r.list_cnt = list_cnt;
+    r.ext_ids = ext_ids;
+    r.out_ids = out_ids;
+    r.out_dists = out_dists;
+    r.out_cnt = out_cnt;
+    r.tile_fail = tile_fail;
+    r.n = n;
+    r.k = k;
+    r.nsplit = f.nsplit;
+    r.caph = f.caph;
+    r.p2max = f.p2max;
+    r.fail_queries = BF_TQ * f.qg;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(bf_rerank_u8_list_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)f.lds_rerank);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(bf_rerank_u8_list_kernel, dim3(nq), dim3(256), f.lds_rerank, s, r);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    // 4. fallback for flagged tile groups (workgroups of clear groups leave at once)
+    e = launch_bf_select_u8_ex(f.fallback, base_i8, aux, queries_padded, cand_fb, cnt_fb, 1, tile_fail, f.qg, s);
+    if (e != hipSuccess) return e;
+    return launch_bf_rerank_ex(f.fallback, SP_L2SQR_SIFT, 128, k, base_u8, queries_padded, cand_fb, cnt_fb, ext_ids, out_ids,
+                               out_dists, out_cnt, tile_fail, BF_TQ * f.qg, s);
+}
+
 hipError_t launch_row_aux_f32(const float* base, int n, int ldb, int dim, int space, float* aux,
                               hipStream_t s) {
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(row_aux_f32_kernel, dim3((n + 3) / 4), dim3(256), 0, s, base, n, ldb, dim, space, aux);
     return hipGetLastError();
 }
-hipError_t launch_prepare_u8(const uint8_t* base, int n, uint8_t* rows_i8, int32_t* aux, hipStream_t s) {
+hipError_t launch_prepare_u8(const uint8_t* base, int n, uint8_t* rows_i8, int32_t* aux, int32_t* auxh, hipStream_t s) {
     const int n_pad = bf_u8_rows_padded(n);
-    hipLaunchKernelGGL(prepare_u8_kernel, dim3((n_pad + 3) / 4), dim3(256), 0, s, base, n, n_pad, rows_i8, aux);
+    hipLaunchKernelGGL(prepare_u8_kernel, dim3((n_pad + 3) / 4), dim3(256), 0, s, base, n, n_pad, rows_i8, aux, auxh);
     return hipGetLastError();
 }
 hipError_t launch_pad_rows(const void* src, int rows, int dim, void* dst, int rows_pad, int ld,

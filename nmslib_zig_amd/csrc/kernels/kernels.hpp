@@ -39,7 +39,7 @@ struct BfPlan {
     size_t lds_select, lds_rerank;
 };
 // Fills every field of the plan from (n, dim, nq, k).  is_u8 selects the integer path.
-BfPlan bf_make_plan(int n, int dim, int nq, int k, bool is_u8);
+BfPlan bf_make_plan(int n, int dim, int nq, int k, bool is_u8, int qpad_multiple = BF_TQ);
 inline size_t bf_cand_elems(const BfPlan& p) { return (size_t)p.qpad * p.nsplit * p.cap; }
 // per-(query,split) survivor counts, then the per-query shared thresholds (gthr), then the
 // per-(query,split) counted bounds (gq)
@@ -56,7 +56,7 @@ hipError_t launch_row_aux_f32(const float* base, int n, int ldb, int dim, int sp
 // u8 brute force: rows_i8 [n_pad][128] = re-centred copy (x ^ 0x80), aux [n_pad] = 256*sum(a) - sum(a^2);
 // n_pad = bf_u8_rows_padded(n), pad rows are zero with an aux that can never be selected (see bf_select_u8)
 inline int bf_u8_rows_padded(int n) { return (n + BF_BN - 1) / BF_BN * BF_BN + BF_BN; }
-hipError_t launch_prepare_u8(const uint8_t* base, int n, uint8_t* rows_i8, int32_t* aux, hipStream_t s);
+hipError_t launch_prepare_u8(const uint8_t* base, int n, uint8_t* rows_i8, int32_t* aux, int32_t* auxh, hipStream_t s);
 // Copy [rows][dim] -> [rows_pad][ld] with zero fill (elem = 4 or 1 bytes).
 hipError_t launch_pad_rows(const void* src, int rows, int dim, void* dst, int rows_pad, int ld,
                            int elem_bytes, hipStream_t s);
@@ -82,6 +82,35 @@ hipError_t launch_query_aux_cosc(const float* orig, const float* centred, int nq
 hipError_t launch_bf_select_u8(const BfPlan& p, const uint8_t* base_i8, const int32_t* aux,
                                const uint8_t* queries_padded, unsigned long long* cand,
                                int* cand_cnt, hipStream_t s);
+// ... over every tile_stride-th 64-row tile only, and/or only for the query-tile groups flagged in tile_fail
+hipError_t launch_bf_select_u8_ex(const BfPlan& p, const uint8_t* base_i8, const int32_t* aux,
+                                  const uint8_t* queries_padded, unsigned long long* cand, int* cand_cnt,
+                                  int tile_stride, const int* tile_fail, int fail_group, hipStream_t s);
+
+// uint8 fast path for large batches (bf_kernels.hip: sample pass -> fixed-threshold scan -> list re-rank with
+// verification -> adaptive fallback for flagged tile groups).  Exact like the adaptive path.
+struct BfU8Fast {
+    bool use;
+    int qg;                    // query groups of 32 per wave: a workgroup serves 128 * qg queries
+    int qpad, nqt;             // queries padded to 128 * qg; scan query tiles
+    int stride, r;             // sample = every stride-th tile; threshold = r-th best score of the sample
+    int nsplit, tps, caph;     // scan: row splits, 64-row tiles per split, list capacity per (query, split, half)
+    int p2max;
+    size_t lds_scan, lds_thr, lds_rerank;
+    int s_nsplit, s_tps;       // sample pass: splits and sample tiles per split
+    BfPlan fallback;           // plan of the adaptive kernel for the fallback
+};
+inline size_t bf_u8_top8_elems(const BfU8Fast& f) { return (size_t)f.qpad * f.s_nsplit * 2 * 8; }
+BfU8Fast bf_u8_fast_plan(int n, int nq, int k);
+inline size_t bf_u8_list_elems(const BfU8Fast& f) { return (size_t)f.qpad * f.nsplit * 2 * f.caph; }
+inline size_t bf_u8_listcnt_elems(const BfU8Fast& f) { return (size_t)f.qpad * f.nsplit * 2; }
+hipError_t launch_bf_u8_fast(const BfU8Fast& f, int n, int nq, int k, const uint8_t* base_u8, const uint8_t* base_i8,
+                             const int32_t* aux, const int32_t* auxh, const uint8_t* queries_padded,
+                             int* top8, unsigned long long* cand_fb, int* cnt_fb,
+                             int* thr, uint32_t* list, int* list_cnt, int* tile_fail, const int32_t* ext_ids,
+                             int32_t* out_ids, float* out_dists, int32_t* out_cnt, hipEvent_t scan_begin,
+                             hipEvent_t scan_end, hipStream_t s);
+
 // Direct (VALU) selection for spaces with no inner-product form (l1, linf).
 hipError_t launch_bf_select_direct_f32(const BfPlan& p, int space, const float* base,
                                        const float* queries_padded, unsigned long long* cand,
@@ -91,6 +120,12 @@ hipError_t launch_bf_rerank(const BfPlan& p, int space, int dim, int k, const vo
                             const void* queries_padded, const unsigned long long* cand,
                             const int* cand_cnt, const int32_t* ext_ids, int32_t* out_ids,
                             float* out_dists, int32_t* out_cnt, hipStream_t s);
+
+hipError_t launch_bf_rerank_ex(const BfPlan& p, int space, int dim, int k, const void* base,
+                               const void* queries_padded, const unsigned long long* cand,
+                               const int* cand_cnt, const int32_t* ext_ids, int32_t* out_ids,
+                               float* out_dists, int32_t* out_cnt, const int* tile_fail, int fail_queries,
+                               hipStream_t s);
 
 // one pair, one wave (nmslib_get_distance)
 hipError_t launch_pair_distance(int space, const void* a, const void* b, int dim, float* out,

@@ -317,3 +317,33 @@ def test_uncentred_data(space, offset):
     want_sim = got_sim.astype(np.float32)
     have_sim = np.cos(ds.astype(np.float64)) if space == "angulardist" else 1.0 - ds.astype(np.float64)
     assert np.all(np.abs(have_sim - want_sim) <= (1e-6 if space == "angulardist" else res))   # (acosf adds its own ulps)
+
+
+@pytest.mark.parametrize("kind", ["sift_like", "heavy_ties"])
+def test_u8_fast_path_large_batch_bit_exact(kind):
+    """Batches of >= 512 queries on >= 128k rows take the sample-threshold + streaming-scan path (bf_scan_u8_kernel);
+    it must stay bit-exact.  heavy_ties: a 3-symbol alphabet makes thousands of rows share the threshold score, the
+    lists overflow and the flagged query tiles are redone by the adaptive kernel -- still exact, incl. tie order."""
+    n, nq, k = 140000, 640, 100
+    if kind == "sift_like":
+        U, UQ = refio.s_sift_like(n, 91), refio.s_sift_like(nq, 92)
+    else:
+        rng = np.random.default_rng(11)
+        U = (rng.integers(0, 3, (n, 128)) * 50).astype(np.uint8)
+        UQ = (rng.integers(0, 3, (nq, 128)) * 50).astype(np.uint8)
+        U[5000:5300] = U[9]
+        UQ[0] = U[9]
+    idx = make_index("l2sqr_sift", "seq_search", U)
+    ids, ds, cnt = idx.knnQueryBatch(UQ, k)
+    assert (cnt == k).all()
+    sel = np.r_[0:24, nq - 24:nq]                                  # oracle on a sample of the queries (CPU time)
+    opos, odist, _ = orc.seq_search("l2sqr_sift", U, UQ[sel], k)
+    np.testing.assert_array_equal(ds[sel], odist)
+    np.testing.assert_array_equal(ids[sel], opos)
+    # the adaptive path (small batches) gives the same rows for the same queries
+    ids2, ds2, _ = idx.knnQueryBatch(UQ[:100], k)
+    np.testing.assert_array_equal(ids2, ids[:100])
+    np.testing.assert_array_equal(ds2, ds[:100])
+    ids3, ds3, _ = idx.knnQueryBatch(UQ, 7)                        # another k through the fast path
+    np.testing.assert_array_equal(ids3, ids[:, :7])
+    idx.close()
