@@ -50,6 +50,11 @@ WORKLOADS = {
                  desc="l2sqr_sift 1Mx128 u8 k=100 batch=4096 (BASELINE configs[3])"),
     "cos768": dict(space="cosinesimil", method="hnsw", dim=768, batch=8192, k=10,
                    desc="HNSW cosinesimil {n}x{dim} f32 M=16 efS={ef} k=10 batch={batch} (one shard of BASELINE configs[4])"),
+    # the sharded form of C5, scaled to what a bench run can build: rows_per_gpu fixed (weak), every rank generates
+    # and indexes only its own rows, per-shard top-k all-gathered over RCCL and merged
+    "cos768x": dict(space="cosinesimil", method="hnsw", dim=768, batch=8192, k=10,
+                    desc="HNSW cosinesimil {n}x{dim} f32 sharded {world} ways, M=16 efS={ef} k=10 batch={batch} "
+                         "(BASELINE configs[4] at {rpg} rows per GPU)"),
 }
 
 
@@ -64,11 +69,13 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", choices=["all"] + list(WORKLOADS), default="all")
+    ap.add_argument("--rows-per-gpu", type=int, default=1_000_000, help="cos768x: rows indexed by every rank")
     ap.add_argument("--n", type=int, default=1_000_000)
     ap.add_argument("--dim", type=int, default=None)
     ap.add_argument("--batch", type=int, default=None)
     ap.add_argument("--k", type=int, default=None)
     ap.add_argument("--ef", type=int, default=128)
+    ap.add_argument("--ef-sweep", default="", help="hnsw / cos768: extra efSearch values measured on the same index, e.g. 256,512,1000")
     ap.add_argument("--rank", type=int, default=64, help="cos768: latent rank of the synthetic rows")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--index-cache", default="", help="hnsw, 1 GPU: save the built index here / load it if present")
@@ -91,6 +98,27 @@ def s_768(n, dim, seed, rank=64, chunk=1 << 18):
         x += 0.1 * rng.standard_normal((hi - lo, dim), dtype=np.float32)
         x /= np.linalg.norm(x, axis=1, keepdims=True)
         out[lo:hi] = x
+    return out
+
+
+def s_768_rows(lo, hi, dim, seed, rank=64, chunk=1 << 18):
+    """Rows [lo, hi) of the S-768 family with one generator per 2^18-row chunk, so that every rank of a sharded run can
+    produce exactly its own rows (the 100M x 768 corpus of C5 never exists in one place)."""
+    A = np.random.default_rng(45).standard_normal((dim, rank)).astype(np.float32)
+    out = np.empty((hi - lo, dim), np.float32)
+    c0 = lo // chunk
+    pos = lo
+    while pos < hi:
+        c = pos // chunk
+        rng = np.random.default_rng([seed, c])
+        m = min(chunk, (c + 1) * chunk) - c * chunk
+        x = rng.standard_normal((m, rank), dtype=np.float32) @ A.T
+        x += 0.1 * rng.standard_normal((m, dim), dtype=np.float32)
+        x /= np.linalg.norm(x, axis=1, keepdims=True)
+        a0, a1 = pos - c * chunk, min(hi, (c + 1) * chunk) - c * chunk
+        out[pos - lo:pos - lo + (a1 - a0)] = x[a0:a1]
+        pos += a1 - a0
+    del c0
     return out
 
 
@@ -168,6 +196,40 @@ def reference_legs(w, X, Q, ef, want_baseline, cpu_sample, gt_sample):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def gpu_exact_ground_truth(space, Xs, lo, hi, Q, ngt, kk, cx):
+    """Exact scan of the (possibly sharded) corpus for the first ngt queries: every rank scans its own rows, the
+    per-shard lists are all-gathered and merged like the timed path.  Rank 0 gets (ids, dists); others None.
+    The scan itself is checked against the reference's seq_search in the bruteforce / sift workloads and in tests/."""
+    import torch
+    import torch.distributed as dist
+    import nmslib_zig_amd as nz
+    bf = nz.Index(space, "seq_search")
+    bf.addDenseBatch(Xs, np.arange(lo, hi, dtype=np.int32))
+    bf.buildIndex()
+    dq = torch.from_numpy(np.ascontiguousarray(Q[:ngt])).to(cx.dev)
+    pack = torch.empty((2, ngt, kk), dtype=torch.int32, device=cx.dev)
+    cnt = torch.empty((ngt,), dtype=torch.int32, device=cx.dev)
+    st = torch.cuda.current_stream()
+    bf.knn_device(dq.data_ptr(), ngt, Q.shape[1], kk, pack[0].data_ptr(), pack[1].data_ptr(), cnt.data_ptr(), st.cuda_stream)
+    torch.cuda.synchronize()
+    bf.close()
+    if cx.world == 1:
+        return pack[0].cpu().numpy(), pack[1].view(torch.float32).cpu().numpy()
+    g = torch.empty((cx.world * 2, ngt, kk), dtype=torch.int32, device=cx.dev)
+    if cx.backend == "nccl":
+        dist.all_gather_into_tensor(g, pack)
+    else:
+        gh = torch.empty(g.shape, dtype=g.dtype)
+        dist.all_gather_into_tensor(gh, pack.cpu())
+        g.copy_(gh)
+    m_ids = torch.empty((ngt, kk), dtype=torch.int32, device=cx.dev)
+    m_ds = torch.empty((ngt, kk), dtype=torch.float32, device=cx.dev)
+    nz._check(nz.lib().nmslib_gpu_merge_topk_strided(g.data_ptr() + ngt * kk * 4, g.data_ptr(), 2 * ngt * kk, cx.world, ngt, kk,
+                                                     m_ds.data_ptr(), m_ids.data_ptr(), st.cuda_stream))
+    torch.cuda.synchronize()
+    return (m_ids.cpu().numpy(), m_ds.cpu().numpy()) if cx.rank == 0 else (None, None)
+
+
 # ------------------------------------------------------------------------------------------------------------
 def run_workload(a, name, cx):
     import torch
@@ -188,14 +250,21 @@ def run_workload(a, name, cx):
     u8 = space == "l2sqr_sift"
     rank, world, dev = cx.rank, cx.world, cx.dev
 
+    sharded_gen = name == "cos768x"
+    if sharded_gen:
+        n = a.rows_per_gpu * world
     note(f"[{name}] generating data: n={n} dim={dim}")
+    lo, hi = rank * n // world, (rank + 1) * n // world          # this rank's row shard
     if name == "sift":
         X, Q = refio.s_sift_like(n, 44), refio.s_sift_like(nq, 45)
     elif name == "cos768":
         X, Q = s_768(n, dim, 46, a.rank), s_768(nq, dim, 47, a.rank)
+    elif sharded_gen:
+        Xs, Q = s_768_rows(lo, hi, dim, 46, a.rank), s_768_rows(0, nq, dim, 47, a.rank)   # own rows only
     else:
         X, Q = refio.s_lowrank(n, dim, 42), refio.s_lowrank(nq, dim, 43)
-    lo, hi = rank * n // world, (rank + 1) * n // world          # this rank's row shard
+    if not sharded_gen:
+        Xs = X[lo:hi]
     cache = a.index_cache if (method == "hnsw" and world == 1 and single) else ""
     build_kw = {"gpu_build": a.gpu_build} if a.gpu_build >= 0 else {}
     build_kw.update(dict(kv.split("=") for kv in a.index_extra.split(",") if kv))
@@ -209,7 +278,7 @@ def run_workload(a, name, cx):
         idx = nz.Index(space, method, data_type="DenseUInt8Vector" if u8 else "DenseVector",
                        dist_type="Int" if u8 else "Float")
         ids = np.arange(lo, hi, dtype=np.int32)                  # external id = global row
-        (idx.addUInt8Batch if u8 else idx.addDenseBatch)(X[lo:hi], ids)
+        (idx.addUInt8Batch if u8 else idx.addDenseBatch)(Xs, ids)
         if method == "hnsw":
             idx.buildIndex(M=16, efConstruction=200, **build_kw)
             graph_build_s = idx.stats()["build_seconds"]
@@ -270,6 +339,12 @@ def run_workload(a, name, cx):
     res_ids = (m_ids if world > 1 else d_ids).cpu().numpy()
     res_ds = (m_ds if world > 1 else d_ds).cpu().numpy()
     counters = idx.read_counters(nq) if method == "hnsw" else None
+    gpu_gt = None
+    if sharded_gen or (name == "cos768" and n > 1_000_000):
+        # the reference's sequential scan of tens of GB is out of reach of a bench run: exact GPU scan instead
+        note(f"[{name}] exact GPU scan for the ground truth")
+        ngt = min(a.gt_sample, nq)
+        gpu_gt = gpu_exact_ground_truth(space, Xs, lo, hi, Q, ngt, k + 22, cx)
     if rank != 0:
         idx.close()
         return None
@@ -307,7 +382,8 @@ def run_workload(a, name, cx):
     out = {
         "metric": {"sift": f"queries/sec @ recall@{k}, {n} x 128-D u8 l2sqr_sift, batch={nq}",
                    "hnsw": f"queries/sec @ recall@{k}, {n} x {dim}-D L2 HNSW, batch={nq}; HBM GB/s vs peak",
-                   "cos768": f"queries/sec @ recall@{k}, {n} x {dim}-D cosinesimil HNSW, batch={nq}"}.get(
+                   "cos768": f"queries/sec @ recall@{k}, {n} x {dim}-D cosinesimil HNSW, batch={nq}",
+                   "cos768x": f"queries/sec @ recall@{k}, {n} x {dim}-D cosinesimil HNSW sharded {world} ways, batch={nq}"}.get(
                        name, "queries/sec @ recall@10, 1M x 128-D L2, batch=1024; HBM GB/s vs peak"),
         "value": round(a.steps * nq / elapsed, 1),
         "unit": "queries/s",
@@ -316,15 +392,15 @@ def run_workload(a, name, cx):
         "warmup": a.warmup,
         "ms_per_step": round(elapsed / a.steps * 1e3, 4),
         "higher_is_better": True,
-        "scaling": "strong",
+        "scaling": "weak" if sharded_gen else "strong",
         "vs_baseline": None,
         "dtype": "u8" if u8 else "f32",
         "data": "synthetic",
         "config": {
-            "workload": w["desc"].format(ef=a.ef, n=n, dim=dim, batch=nq),
+            "workload": w["desc"].format(ef=a.ef, n=n, dim=dim, batch=nq, world=world, rpg=hi - lo),
             "rows": n, "dim": dim, "batch": nq, "k": k, "rows_per_gpu": rows_local,
             "dataset": "S-sift-like seeds 44/45" if u8 else (f"S-768 rank-{a.rank} + 0.1 noise, unit rows, seeds 46/47"
-                                                             if name == "cos768" else
+                                                             if name in ("cos768", "cos768x") else
                                                              "S-lowrank rank-16 + 0.1 noise, seeds 42/43"),
             "sharding": (f"rows/{world} + {'RCCL' if cx.backend == 'nccl' else cx.backend} all-gather of per-shard top-k"
                          if world > 1 else "single GPU"),
@@ -335,6 +411,29 @@ def run_workload(a, name, cx):
     }
     if graph_build_s is not None:
         out["config"]["graph_build_s"] = round(graph_build_s, 2)
+
+    # ---- other efSearch values on the same index (recall filled in below) -----------------------------------------
+    sweep = []
+    if method == "hnsw" and a.ef_sweep and world == 1:
+        for ef2 in [int(x) for x in a.ef_sweep.split(",") if x]:
+            idx.setQueryTimeParams(efSearch=ef2)
+            step()
+            sync()
+            idx.kernel_timing(enable=True)
+            t1 = time.perf_counter()
+            for _ in range(a.steps):
+                step()
+            sync()
+            el2 = time.perf_counter() - t1
+            kms, kl = idx.kernel_timing(enable=False, collect=True)
+            c2 = [c.astype(np.float64) for c in idx.read_counters(nq)]
+            ab = float((c2[0] * dim * 4 + c2[1] * 33 * 4 + c2[2] * 17 * 4 + c2[0]).sum())
+            ks = kms / 1e3 / max(1, kl)
+            sweep.append({"ef": ef2, "value": round(a.steps * nq / el2, 1), "ms_per_step": round(el2 / a.steps * 1e3, 4),
+                          "kernel_ms": round(ks * 1e3, 4), "hbm_gbs": round(ab / ks / 1e9, 1),
+                          "frac": round(ab / ks / 1e9 / PEAK_HBM_GBS, 4), "ndc_per_query": round(float(c2[0].mean()), 1),
+                          "_ids": d_ids.cpu().numpy().copy()})
+        idx.setQueryTimeParams(efSearch=a.ef)
 
     # ---- the reference-ABI entry: nmslib_knn_query_batch, host pointers, PCIe inside the call --------------
     if world == 1:
@@ -357,13 +456,23 @@ def run_workload(a, name, cx):
 
     # ---- recall against an independent exact ground truth + the CPU baseline ---------------------------------
     # (cos768 beyond 200k rows: the reference's 768-D build takes too long for a bench run; exact scan only)
-    want_base = world == 1 and not a.no_cpu_baseline and not (name == "cos768" and n > 200_000)
+    want_base = world == 1 and not a.no_cpu_baseline and not (name in ("cos768", "cos768x") and n > 200_000)
     try:
-        gt_ids, gt_d, base = reference_legs(w, X, Q, a.ef, want_base, a.cpu_sample, a.gt_sample)
+        if gpu_gt is not None:
+            gt_ids, gt_d = gpu_gt
+            base = None
+            gt_label = f"exact GPU scan (seq_search over the same rows), first {len(gt_ids)} queries, tie-extended at k+22"
+        else:
+            gt_ids, gt_d, base = reference_legs(w, Xs if sharded_gen else X, Q, a.ef, want_base, a.cpu_sample, a.gt_sample)
+            gt_label = None
         m = len(gt_ids)
         gdd = gt_d ** 2 if (method == "hnsw" and space == "l2") else gt_d      # HNSW-l2 returns squared L2
         out["recall_at_k"] = round(float(refio.recall_nmslib(res_ids[:m], gt_ids, gdd, k, integer=u8)), 4)
-        out["recall_ground_truth"] = f"reference seq_search (oracle/_ref), exact, first {m} queries, tie-extended at k+22"
+        out["recall_ground_truth"] = gt_label or f"reference seq_search (oracle/_ref), exact, first {m} queries, tie-extended at k+22"
+        for rec_ in sweep:
+            rec_["recall_at_k"] = round(float(refio.recall_nmslib(rec_.pop("_ids")[:m], gt_ids, gdd, k)), 4)
+        if sweep:
+            out["ef_sweep"] = sweep
         if method != "hnsw":
             # the exact method must also reproduce the reference's distances on the sample (1e-5 rel; integers exact)
             ok = np.array_equal(res_ds[:m], gt_d[:, :k]) if u8 else np.allclose(res_ds[:m], gt_d[:, :k], rtol=1e-5, atol=1e-6)
@@ -371,13 +480,28 @@ def run_workload(a, name, cx):
         if base is not None:
             out["cpu_baseline"] = base
     except Exception as e:  # the baseline must never take the GPU number down with it
+        for rec_ in sweep:
+            rec_.pop("_ids", None)
         out["recall_at_k"] = None
         out["cpu_baseline"] = {"value": None, "unit": "queries/s", "cores": 0, "kind": "reference", "sample": f"failed: {e}"}
     return out
 
 
+def heartbeat():
+    """a line on stderr every minute: long host-side phases (data generation, 768-D builds) must not look hung"""
+    import threading
+
+    def run():
+        t0 = time.time()
+        while True:
+            time.sleep(60)
+            note(f"... still working ({time.time() - t0:.0f}s)")
+    threading.Thread(target=run, daemon=True).start()
+
+
 def main():
     a = parse()
+    heartbeat()
     # --gpus N without a torchrun environment: launch the N ranks ourselves (before anything touches the GPU)
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         port = 29500 + (os.getpid() % 2000)
@@ -410,7 +534,7 @@ def main():
     if a.workload == "all":
         out = run_workload(a, "bruteforce", cx)
         subs = {}
-        for name in ("hnsw", "sift"):
+        for name in ("hnsw", "sift", "cos768x"):
             r = run_workload(a, name, cx)
             if r is not None:
                 subs[name] = r

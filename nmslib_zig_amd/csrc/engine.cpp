@@ -137,6 +137,7 @@ Engine::~Engine() {
     }
     for (hipEvent_t e : shard_events_) (void)hipEventDestroy(e);
     if (shard_ready_) (void)hipEventDestroy(shard_ready_);
+    if (pinned_) (void)hipHostFree(pinned_);
     if (stream_) (void)hipStreamDestroy(stream_);
 }
 
@@ -450,7 +451,9 @@ bool Engine::use_gpu_build() const {
     if (loaded_graph_ || method_ != Method::Hnsw) return false;
     if (bp_.gpu_build >= 0) return bp_.gpu_build != 0;
     // auto: indexThreadQty=1 asks for the reference's sequential insertion order (bit-identical graph,
-    // host builder); anything else is the concurrent build, whose schedule is free -> the GPU
+    // host builder); anything else is the concurrent build, whose schedule is free -> the GPU, unless the
+    // parameters exceed what its kernels hold in LDS (the host builder has the reference's "no limits")
+    if (bp_.efConstruction > 1024 || bp_.maxM > 62 || bp_.maxM0 > 126) return false;
     return bp_.threads != 1;
 }
 
@@ -1085,14 +1088,14 @@ void Engine::knn_hnsw_old(const void* d_queries, size_t nq, size_t k, int32_t* d
             ws_old_a_.ensure(std::max<size_t>(16, m * hnsw_old_ws_a(p)));
             ws_old_r_.ensure(std::max<size_t>(16, m * hnsw_old_ws_r(p)));
             ws_old_heap_.ensure(std::max<size_t>(16, m * hnsw_old_ws_heap(p)));
-            if (q0 == 0 && attempt == 0) prof_begin(stream);
+            if (q0 == 0) prof_begin(stream);  // all slices of one attempt are one timed interval
             hip_check(launch_hnsw_search_old(dg_, p, static_cast<const char*>(d_queries) + q0 * qbytes, bitset,
                                              ws_old_a_.ptr(), ws_old_r_.ptr(), ws_old_heap_.ptr(), d_ids + q0 * k,
                                              d_dists + q0 * k, cnt + q0, ws_ndc_.as<int32_t>() + co + q0,
                                              ws_hops_.as<int32_t>() + co + q0, ws_hops_up_.as<int32_t>() + co + q0,
                                              ws_status_.as<int32_t>() + co + q0, stream),
                       "hnsw_search_old");
-            if (q0 == 0 && attempt == 0) prof_end(stream);
+            if (q0 + slice >= nq) prof_end(stream);
         }
         have_counters_ = true;
         // status 1: the LDS visited table filled up -> HBM bitsets; status 2: the candidate heap outgrew its bound
@@ -1110,26 +1113,43 @@ void Engine::knn_hnsw_old(const void* d_queries, size_t nq, size_t k, int32_t* d
     throw EngineError(Err::QueryExecutionFailed, "SearchOld: queue workspaces exhausted");
 }
 
+// Pinned host staging buffer (grow-only): PCIe copies from/to pageable memory are staged by the runtime in small
+// chunks and block the calling thread; one pinned block makes the batch's H2D and D2H a single DMA each.
+void* Engine::pinned(size_t bytes) {
+    if (bytes <= pinned_bytes_ && pinned_) return pinned_;
+    if (pinned_) (void)hipHostFree(pinned_);
+    pinned_ = nullptr;
+    pinned_bytes_ = 0;
+    hip_check(hipHostMalloc(&pinned_, bytes, hipHostMallocDefault), "hipHostMalloc");
+    pinned_bytes_ = bytes;
+    return pinned_;
+}
+
 void Engine::knn_host(const void* queries, size_t nq, size_t elem_count, size_t k, std::vector<int32_t>& ids,
                       std::vector<float>& dists, std::vector<int32_t>& cnt) {
     if (!created_) throw EngineError(Err::IndexBuildFailed, "Index not built");
     if (dirty_) finalize();
     check_device();
     const size_t qbytes = nq * elem_count * elem_bytes();
+    const size_t rbytes = nq * k * 4;
+    // device: queries | ids | dists | counts in ONE block each way; host: one pinned block
     ws_q_.ensure(qbytes);
-    ws_ids_.ensure(nq * k * 4);
-    ws_dists_.ensure(nq * k * 4);
-    ws_outcnt_.ensure(nq * 4);
-    hip_check(hipMemcpyAsync(ws_q_.ptr(), queries, qbytes, hipMemcpyHostToDevice, stream_), "queries H2D");
-    knn_device(ws_q_.ptr(), nq, elem_count, k, ws_ids_.as<int32_t>(), ws_dists_.as<float>(), ws_outcnt_.as<int32_t>(),
-               stream_);
+    ws_ids_.ensure(2 * rbytes + nq * 4);
+    int32_t* d_ids = ws_ids_.as<int32_t>();
+    float* d_dists = reinterpret_cast<float*>(d_ids + nq * k);
+    int32_t* d_cnt = d_ids + 2 * nq * k;
+    char* hp = static_cast<char*>(pinned(std::max(qbytes, 2 * rbytes + nq * 4)));
+    std::memcpy(hp, queries, qbytes);
+    hip_check(hipMemcpyAsync(ws_q_.ptr(), hp, qbytes, hipMemcpyHostToDevice, stream_), "queries H2D");
+    knn_device(ws_q_.ptr(), nq, elem_count, k, d_ids, d_dists, d_cnt, stream_);
+    hip_check(hipMemcpyAsync(hp, d_ids, 2 * rbytes + nq * 4, hipMemcpyDeviceToHost, stream_), "results D2H");
+    hip_check(hipStreamSynchronize(stream_), "knn");
     ids.resize(nq * k);
     dists.resize(nq * k);
     cnt.resize(nq);
-    hip_check(hipMemcpyAsync(ids.data(), ws_ids_.ptr(), nq * k * 4, hipMemcpyDeviceToHost, stream_), "ids D2H");
-    hip_check(hipMemcpyAsync(dists.data(), ws_dists_.ptr(), nq * k * 4, hipMemcpyDeviceToHost, stream_), "dists D2H");
-    hip_check(hipMemcpyAsync(cnt.data(), ws_outcnt_.ptr(), nq * 4, hipMemcpyDeviceToHost, stream_), "cnt D2H");
-    hip_check(hipStreamSynchronize(stream_), "knn");
+    std::memcpy(ids.data(), hp, rbytes);
+    std::memcpy(dists.data(), hp + rbytes, rbytes);
+    std::memcpy(cnt.data(), hp + 2 * rbytes, nq * 4);
 }
 
 size_t Engine::range_host(const void* query, size_t elem_count, double radius, size_t capacity, int32_t* ids,

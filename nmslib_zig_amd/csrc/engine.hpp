@@ -189,6 +189,9 @@ class Engine {
     int forced_device_ = -1;
     int gpu_shards_ = -1;  // index parameter: -1 unset, 0 = all visible devices, N = that many
     DevBuf ws_sh_ids_, ws_sh_d_;
+    void* pinned(size_t bytes);
+    void* pinned_ = nullptr;
+    size_t pinned_bytes_ = 0;
     void check_device();
     void ensure_graph();
     void upload_rows();

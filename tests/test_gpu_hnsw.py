@@ -272,3 +272,19 @@ def test_searchold_exact_under_heavy_ties_u8():
         np.testing.assert_array_equal(ndc, ondc)
         np.testing.assert_array_equal(hops, ohops)
     idx.close()
+
+
+def test_zig_batch_call_sequence_replayed_in_c(tmp_path):
+    """zig/nmslib_gpu_batch.zig cannot be compiled here (no Zig toolchain): its exact C call sequence -- lib.zig's
+    create-then-add order, nmslib_initialize_pool, ONE nmslib_knn_query_batch over a flat copy with caller-owned
+    buffers, dense and packed uint8 -- is replayed by a plain C program against the library and must equal the
+    reference's per-query sequence (lib.zig:889-931)."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "zig_batch_sequence_check")
+    libdir = os.path.join(root, "nmslib_zig_amd")
+    subprocess.check_call(["gcc", "-std=c11", "-O1", os.path.join(root, "tests", "zig_batch_sequence_check.c"), "-o", exe,
+                           "-L" + libdir, "-lnmslib_c", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0 and "zig batch sequence ok" in out.stdout, out.stdout + out.stderr

@@ -70,7 +70,7 @@ def test_gpu_build_invariants_and_recall_small(space, tmp_path):
         rec[mode] = refio.recall_nmslib(ids, ei, ed, k, integer=(space == "l2sqr_sift"))
         idx.close()
     print("recall host/gpu build:", rec)
-    assert rec[1] >= rec[0] - (0.03 if space == "l2sqr_sift" else 0.01), rec   # (sift-like data sits at ~0.6: noisier)
+    assert rec[1] >= rec[0] - 0.01, rec
     assert space == "l2sqr_sift" or rec[1] >= 0.95, rec     # (uniform-ish u8 data is hard at ef=64 for both)
 
 
@@ -183,3 +183,27 @@ def test_gpu_build_hub_targets_many_requests_deterministic(tmp_path):
     check_invariants(graphs[0], 8, 8, 16)
     assert rec["gpu0"] >= rec["host"] - 0.02 and rec["gpu0"] >= 0.9, rec
     assert selfhit["gpu0"] >= selfhit["host"] - 0.05, selfhit
+
+
+def test_c5_graph_quality_1m_768_cosine_vs_reference_graph():
+    """C5 (HNSW cosinesimil, 768-D): 1M x 768 S-768 rows (rank-64 latent: a hard set -- the REFERENCE's own graph reaches
+    recall@10 = 0.44 at efSearch=128, tests/golden/c5_ref_1m768.json, produced by tools/c5_recall.py from the real
+    reference).  The GPU-built graph must match that graph's recall at equal efSearch on the same 512 queries."""
+    import json
+    import os
+    from tools.c5_recall import s_768
+    ref = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "c5_ref_1m768.json")))
+    n, dim, nq, k = ref["n"], ref["dim"], ref["nq"], ref["k"]
+    X, Q = s_768(n, dim, 46, ref["rank"], ref["noise"]), s_768(nq, dim, 47, ref["rank"], ref["noise"])
+    bf = make_index("cosinesimil", "seq_search", X)
+    gi, gd, _ = bf.knnQueryBatch(Q, k + 22)
+    bf.close()
+    idx = make_index("cosinesimil", "hnsw", X, M=ref["M"], efConstruction=ref["efC"], gpu_build=1)
+    got = {}
+    for ef in (128, 512, 1000):
+        idx.setQueryTimeParams(efSearch=ef)
+        ids, _, _ = idx.knnQueryBatch(Q, k)
+        got[ef] = refio.recall_nmslib(ids, gi, gd, k)
+    idx.close()
+    for ef, r in got.items():
+        assert r >= ref["recall"][str(ef)] - 0.001, (got, ref["recall"])
