@@ -38,6 +38,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_I8_MFMA_TOPS = 5000.0     # i8 = 2x bf16 dense (~2.5 PF) per MI355X_MICROARCH.md
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # bf16 dense
 PEAK_HBM_GBS = 8000.0          # HBM3E spec
 
 WORKLOADS = {
@@ -106,19 +107,17 @@ def s_768_rows(lo, hi, dim, seed, rank=64, chunk=1 << 18):
     produce exactly its own rows (the 100M x 768 corpus of C5 never exists in one place)."""
     A = np.random.default_rng(45).standard_normal((dim, rank)).astype(np.float32)
     out = np.empty((hi - lo, dim), np.float32)
-    c0 = lo // chunk
     pos = lo
     while pos < hi:
         c = pos // chunk
         rng = np.random.default_rng([seed, c])
-        m = min(chunk, (c + 1) * chunk) - c * chunk
+        m = chunk
         x = rng.standard_normal((m, rank), dtype=np.float32) @ A.T
         x += 0.1 * rng.standard_normal((m, dim), dtype=np.float32)
         x /= np.linalg.norm(x, axis=1, keepdims=True)
         a0, a1 = pos - c * chunk, min(hi, (c + 1) * chunk) - c * chunk
         out[pos - lo:pos - lo + (a1 - a0)] = x[a0:a1]
         pos += a1 - a0
-    del c0
     return out
 
 
@@ -339,6 +338,7 @@ def run_workload(a, name, cx):
     res_ids = (m_ids if world > 1 else d_ids).cpu().numpy()
     res_ds = (m_ds if world > 1 else d_ds).cpu().numpy()
     counters = idx.read_counters(nq) if method == "hnsw" else None
+    last_path = int(idx.stats().get("last_path", 0))
     gpu_gt = None
     if sharded_gen or (name == "cos768" and n > 1_000_000):
         # the reference's sequential scan of tens of GB is out of reach of a bench run: exact GPU scan instead
@@ -362,7 +362,17 @@ def run_workload(a, name, cx):
     elif u8:
         ops = 2.0 * nq * rows_local * 128
         roof = {"bound": "mfma", "achieved": round(ops / kern_s / 1e12, 2), "peak": PEAK_I8_MFMA_TOPS, "unit": "TOP/s",
-                "kernel": "bf_select_u8_kernel"}
+                "kernel": "bf_scan_u8_kernel" if last_path == 3 else "bf_select_u8_kernel"}
+    elif last_path == 1:
+        # selection on the bf16 matrix cores: every f32 operand split into two bf16, three products per element
+        flops = 2.0 * nq * rows_local * dim             # algorithmic 2*Q*N*D
+        roof = {"bound": "mfma", "achieved": round(flops / kern_s / 1e12, 2), "peak": PEAK_BF16_MFMA_TFLOPS,
+                "unit": "TFLOP/s", "kernel": "bf_scan_f32_kernel",
+                "arithmetic": "bf16 x 3 (f32 rows and queries split into hi + lo bf16; qh.bh + qh.bl + ql.bh, f32 accumulate); "
+                              "exact f32 re-rank",
+                "issued_tflops": round(3 * flops / kern_s / 1e12, 2),
+                "frac_issued": round(3 * flops / kern_s / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4),
+                "vs_f32_mfma_peak": round(flops / kern_s / 1e12 / PEAK_F32_MFMA_TFLOPS, 3)}
     else:
         flops = 2.0 * nq * rows_local * dim             # 2*Q*N*D
         roof = {"bound": "mfma", "achieved": round(flops / kern_s / 1e12, 2), "peak": PEAK_F32_MFMA_TFLOPS,
@@ -374,7 +384,7 @@ def run_workload(a, name, cx):
     if os.path.exists(tr) and n == 1_000_000 and world == 1 and dim == WORKLOADS[name]["dim"] and not a.space:
         try:
             tj = json.load(open(tr))
-            roof["traffic"] = tj.get(name)
+            roof["traffic"] = tj.get(roof["kernel"], tj.get(name))
             roof["traffic_source"] = tj.get("source")
         except Exception:
             pass
@@ -394,7 +404,7 @@ def run_workload(a, name, cx):
         "higher_is_better": True,
         "scaling": "weak" if sharded_gen else "strong",
         "vs_baseline": None,
-        "dtype": "u8" if u8 else "f32",
+        "dtype": "u8" if u8 else ("bf16x3+f32" if last_path == 1 else "f32"),
         "data": "synthetic",
         "config": {
             "workload": w["desc"].format(ef=a.ef, n=n, dim=dim, batch=nq, world=world, rpg=hi - lo),

@@ -80,6 +80,8 @@ typedef struct {
     size_t rows;
     size_t dim;
     size_t shards;         /* row shards behind this handle (index parameter gpu_shards); 1 = single GPU */
+    size_t last_path;      /* selection path of the last brute-force batch: 0 adaptive f32 MFMA, 1 split-bf16 fast path,
+                              2 adaptive int8, 3 int8 fast path; 4 = HNSW */
 } nmslib_gpu_stats_t;
 nmslib_error_t nmslib_gpu_get_stats(nmslib_index_handle_t index, nmslib_gpu_stats_t* out);
 

@@ -693,6 +693,7 @@ nmslib_error_t nmslib_gpu_get_stats(nmslib_index_handle_t handle, nmslib_gpu_sta
     out->rows = e->size();
     out->dim = e->dim();
     out->shards = e->shard_count() ? e->shard_count() : 1;
+    out->last_path = (size_t)e->last_path;
     return NMSLIB_SUCCESS;
 }
 

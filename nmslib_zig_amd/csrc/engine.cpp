@@ -219,6 +219,7 @@ void Engine::reset() {
     shards_.clear();
     dim_ = 0;  // a reset index accepts rows of another dimension
     centred_ = false;
+    have_bf16_ = false;
 }
 
 size_t Engine::memory_usage() const {
@@ -233,7 +234,7 @@ size_t Engine::hbm_bytes() const {
     size_t sh = 0;
     for (const auto& c : shards_) sh += c->hbm_bytes();
     return sh + d_rows_.bytes() + d_rows_i8_.bytes() + d_aux_.bytes() + d_ids_.bytes() + d_links0_.bytes() + d_up_off_.bytes() +
-           d_up_links_.bytes() + d_rownorm_.bytes() + d_rows_sel_.bytes() + d_auxh_.bytes();
+           d_up_links_.bytes() + d_rownorm_.bytes() + d_rows_sel_.bytes() + d_auxh_.bytes() + d_bf_hi_.bytes() + d_bf_lo_.bytes() + d_auxp_.bytes();
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -758,6 +759,25 @@ void Engine::finalize() {
                 hip_check(launch_row_aux_f32(sel_rows, (int)n, ldb_, (int)dim_, space_, d_aux_.as<float>(), stream_),
                           "row aux");
             }
+            // fast path (large batches, D <= 128): bf16 hi / lo tiles of the selection rows + padded aux
+            have_bf16_ = false;
+            d_bf_hi_.release();
+            d_bf_lo_.release();
+            d_auxp_.release();
+            const bool fast_space = space_ == SP_L2 || space_ == SP_NEGDOT ||
+                                    ((space_ == SP_COSINE || space_ == SP_ANGULAR) && !centred_);
+            if (fast_space && dim_ <= 128 && n >= 131072) {
+                const size_t n_pad = (size_t)bf_f32_rows_padded((int)n);
+                d_bf_hi_.ensure(n_pad * 128 * 2);
+                d_bf_lo_.ensure(n_pad * 128 * 2);
+                d_auxp_.ensure(n_pad * 4);
+                const float pad = space_ == SP_L2 ? -INFINITY : 0.f;
+                hip_check(launch_split_bf16(sel_rows, (int)n, (int)n_pad, ldb_, (int)dim_, d_bf_hi_.ptr(), d_bf_lo_.ptr(),
+                                            space_ == SP_NEGDOT ? nullptr : d_aux_.as<float>(), pad, d_auxp_.as<float>(),
+                                            stream_),
+                          "split rows");
+                have_bf16_ = true;
+            }
         }
         hip_check(hipStreamSynchronize(stream_), "finalize");
     } else {
@@ -958,9 +978,54 @@ void Engine::knn_brute(const void* d_queries, size_t nq, size_t k, int32_t* d_id
                                         ws_u8_list_.as<uint32_t>(), ws_u8_listcnt_.as<int>(), tile_fail,
                                         d_ids_.as<int32_t>(), d_ids, d_dists, d_cnt, eb, ee, stream),
                       "bf_u8_fast");
+            last_path = 3;
             return;
         }
     }
+    if (!is_u8() && have_bf16_) {
+        // large batches at D <= 128: split-bf16 MFMA selection with sample-fixed thresholds (bf_scan_f32_kernel)
+        const BfF32Fast f = bf_f32_fast_plan((int)d_n_, dim_eff, (int)nq, (int)k, space_, centred_);
+        if (f.use) {
+            const int ldb = ldb_;
+            ws_qpad_.ensure((size_t)f.qpad * ldb * 4);
+            hip_check(launch_pad_rows(d_queries, (int)nq, dim_eff, ws_qpad_.ptr(), f.qpad, ldb, 4, stream), "pad queries");
+            const float* qsel = ws_qpad_.as<float>();
+            if (centred_) {
+                ws_qsel_.ensure((size_t)f.qpad * ldb * 4);
+                hip_check(launch_center_rows(ws_qpad_.as<float>(), d_mean_.as<float>(), f.qpad, (int)nq, ldb, dim_eff,
+                                             ws_qsel_.as<float>(), stream),
+                          "centre queries");
+                qsel = ws_qsel_.as<float>();
+            }
+            ws_cand_.ensure(bf_cand_elems(f.fallback) * 8);
+            ws_cnt_.ensure(bf_cnt_elems(f.fallback) * 4);
+            ws_f32_q_.ensure((size_t)f.qpad * 128 * 2 * 2);
+            ws_u8_cand_.ensure(bf_f32_top8_elems(f) * 4);
+            ws_u8_thr_.ensure((size_t)f.qpad * 4 + (size_t)f.nqt * 4 + 64);
+            ws_u8_list_.ensure(bf_f32_list_elems(f) * 4);
+            ws_u8_listcnt_.ensure(bf_f32_listcnt_elems(f) * 4);
+            float* thr = ws_u8_thr_.as<float>();
+            int* tile_fail = reinterpret_cast<int*>(thr + f.qpad);
+            char* qh = ws_f32_q_.as<char>();
+            char* ql = qh + (size_t)f.qpad * 128 * 2;
+            hipEvent_t eb = nullptr, ee = nullptr;
+            if (prof_ && prof_events_.size() < 65536) {
+                hip_check(hipEventCreate(&eb), "hipEventCreate");
+                hip_check(hipEventCreate(&ee), "hipEventCreate");
+                prof_events_.emplace_back(eb, ee);
+            }
+            hip_check(launch_bf_f32_fast(f, space_, (int)d_n_, dim_eff, ldb, (int)nq, (int)k, d_rows_.as<float>(),
+                                         centred_ ? d_rows_sel_.as<float>() : d_rows_.as<float>(), d_aux_.as<float>(),
+                                         d_bf_hi_.ptr(), d_bf_lo_.ptr(), d_auxp_.as<float>(), ws_qpad_.as<float>(), qsel, qh, ql,
+                                         ws_u8_cand_.as<float>(), ws_cand_.as<unsigned long long>(), ws_cnt_.as<int>(), thr,
+                                         ws_u8_list_.as<uint32_t>(), ws_u8_listcnt_.as<int>(), tile_fail,
+                                         d_ids_.as<int32_t>(), d_ids, d_dists, d_cnt, eb, ee, stream),
+                      "bf_f32_fast");
+            last_path = 1;
+            return;
+        }
+    }
+    last_path = is_u8() ? 2 : 0;
     BfPlan p = bf_make_plan((int)d_n_, dim_eff, (int)nq, (int)k, is_u8());
     if (d_n_ == 0) p.ldb = is_u8() ? 128 : f32_row_stride(dim_eff);
     const int elem = is_u8() ? 1 : 4;
@@ -1006,6 +1071,7 @@ void Engine::knn_brute(const void* d_queries, size_t nq, size_t k, int32_t* d_id
 void Engine::knn_hnsw(const void* d_queries, size_t nq, size_t k, int32_t* d_ids, float* d_dists, int32_t* d_cnt,
                       hipStream_t stream) {
     const int ef = ef_;
+    last_path = 4;
     // Hnsw::Search, hnsw.cc:724: algoType=old, or hybrid with ef >= 1000, runs SearchOld
     if (algo_ == "old" || (algo_ == "hybrid" && ef >= 1000)) {
         knn_hnsw_old(d_queries, nq, k, d_ids, d_dists, d_cnt, stream);

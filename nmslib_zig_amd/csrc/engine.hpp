@@ -166,6 +166,7 @@ class Engine {
     void collect_profile(double* total_ms, uint64_t* launches);
 
     double upload_seconds = 0, build_seconds = 0;
+    int last_path = 0;  // see nmslib_gpu_stats_t
     size_t hbm_bytes() const;
 
     std::mutex mu;  // serialises finalize + queries on one index
@@ -231,6 +232,8 @@ class Engine {
     hipStream_t stream_ = nullptr;
     DevBuf d_rows_, d_rows_i8_, d_aux_, d_ids_, d_links0_, d_up_off_, d_up_links_, d_rownorm_;
     DevBuf d_auxh_;  // uint8 brute force: aux >> 1 (fast-path scan)
+    DevBuf d_bf_hi_, d_bf_lo_, d_auxp_, ws_f32_q_;  // f32 fast path: bf16 hi / lo tiles of the selection rows, padded aux, split queries
+    bool have_bf16_ = false;
     DevBuf ws_u8_cand_, ws_u8_cnt_, ws_u8_thr_, ws_u8_list_, ws_u8_listcnt_;
     DevBuf d_rows_sel_, d_mean_;  // brute-force L2 on un-centred data: selection copy (rows - column mean) and the mean
     bool centred_ = false;

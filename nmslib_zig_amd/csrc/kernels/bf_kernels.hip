@@ -43,6 +43,8 @@ struct BfArgs {
     int kcs;      // floats staged per K-chunk = min(ldb, 128)
     int nchunks;  // ceil(ldb / 128)
     int dbg;      // NMSLIB_GPU_DEBUG bits (timing experiments only): 1 skip epilogue, 2 skip staging, 4 no stagger, 8 no barrier
+    const int* tile_fail;  // fallback launch of the f32 fast path: query tiles whose group flag is 0 have nothing to do
+    int fail_group;
 };
 
 // row handled by accumulator register r of a lane in half h (C/D map of the 32x32 MFMAs)
@@ -233,6 +235,7 @@ __global__ __launch_bounds__(256, 2) void bf_select_f32_kernel(BfArgs a) {
     const int qt = rest % a.nqt;
     const int split = (rest / a.nqt) * 8 + xcd;
     if (split >= a.nsplit) return;
+    if (a.tile_fail && a.tile_fail[qt / a.fail_group] == 0) return;
 
     constexpr bool kDirect = (MODE == BF_L1 || MODE == BF_LINF);
     constexpr bool kDelay = !kDirect;  // epilogue of stage s overlapped with the MFMAs of s+1
@@ -1247,6 +1250,343 @@ __global__ __launch_bounds__(256) void bf_rerank_u8_list_kernel(RerankListArgs a
 }
 
 // ---------------------------------------------------------------------------------------
+// f32 fast path (large batches, D <= 128; l2 / negdotprod / cosinesimil / angulardist): the uint8 fast path's
+// structure (sample pass -> fixed thresholds -> streaming scan -> list re-rank with verification -> adaptive
+// fallback) with the SELECTION contraction on the bf16 matrix cores.  Every row and query is split into two bf16
+// numbers, x = hi + lo + O(2^-16 |x|), and q.b is taken as qh.bh + qh.bl + ql.bh: three v_mfma_f32_32x32x16_bf16 per 16
+// elements = 3/16 of the matrix-pipe time of the f32 MFMA, f32 accumulation, relative error ~5e-5 per product (the
+// dropped ql.bl term and the split residues).  That error only has to be small against the gap between the k-th and
+// the ~8r-th neighbour (the threshold lets ~70-100 rows through per query, k' = 14 for the adaptive kernel); the
+// re-rank computes the reference formula in f32 on the original rows, and the verification + fallback make the result
+// independent of the approximation: exact like the adaptive path.
+// Workgroup = 8 waves = 256 queries (32 per wave, both bf16 halves of the query fragments resident: 64 VGPRs); rows
+// stream by LDS-DMA into a ring of 32 KB stages (64 rows x 128 x {hi, lo}), 16-byte chunks swizzled on the source side
+// (chunk ^ (row & 15)) so that ds_read_b128 of 16 rows is conflict-free; the L2 norm term enters as the accumulators'
+// initial value, read from LDS straight into the MFMA registers.
+// ---------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+enum ScanMode : int { SC_L2 = 0, SC_DOT = 1, SC_COS = 2 };
+
+struct BfScanF32Args {
+    const __bf16* base_hi;    // [n_pad][128]
+    const __bf16* base_lo;    // [n_pad][128]
+    const float* auxp;        // [n_pad]: l2 -0.5|b|^2, cosine 1/|b|, dot 0; rows >= n: -inf (l2) / 0
+    const __bf16* q_hi;       // [qpad][128]
+    const __bf16* q_lo;
+    const float* thr;         // [qpad] pass <=> score >= thr
+    uint32_t* list;           // [qpad][nsplit][2][caph]
+    int* list_cnt;            // [qpad][nsplit][2]
+    int n, nqt, nsplit, tps, caph;
+    int tile_stride;          // SAMPLE
+    float* top8;              // SAMPLE: [qpad][nsplit][2][8]
+};
+
+template <int MODE, bool SAMPLE, int QG>
+__global__ __launch_bounds__(512, 2) void bf_scan_f32_kernel(BfScanF32Args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, l31 = lane & 31;
+    const int b = blockIdx.x;
+    const int xcd = b & 7, rest = b >> 3;
+    const int qt = rest % a.nqt;
+    const int split = (rest / a.nqt) * 8 + xcd;
+    if (split >= a.nsplit) return;
+
+    constexpr int kRing = 4, kAuxRing = 8, kHalfBytes = BF_BN * 256, kStageBytes = 2 * kHalfBytes;  // hi tile | lo tile
+    char* ring = smem;
+    float* auxr = reinterpret_cast<float*>(ring + kRing * kStageBytes);  // [kAuxRing][BN]
+
+    const int tstr = SAMPLE ? a.tile_stride : 1;
+    const int tiles_all = (a.n + BF_BN - 1) / BF_BN;
+    const int stiles_all = (tiles_all + tstr - 1) / tstr;
+    const int nstages = max(0, min(a.tps, stiles_all - split * a.tps));
+    const int r_begin = split * a.tps * tstr * BF_BN;
+    const int stage_rows = tstr * BF_BN;
+
+    // one stage = 32 DMA pieces of 1 KiB (4 rows x 256 B): wave w issues pieces 4w .. 4w+3 (0..15 hi tile, 16..31 lo tile)
+    auto issue_tile = [&](int stage) __attribute__((always_inline)) {
+        const int slot = stage % kRing;
+        const int row0 = r_begin + stage * stage_rows;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const int j = 4 * wave + jj;
+            const int half = j >> 4, pj = j & 15;     // piece pj of its tile = rows 4*pj .. 4*pj+3
+            const int row = 4 * pj + (lane >> 4);
+            const int c = (lane & 15) ^ (row & 15);
+            const __bf16* src = (half ? a.base_lo : a.base_hi) + (size_t)(row0 + row) * 128 + c * 8;
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(ring + slot * kStageBytes + half * kHalfBytes + pj * 1024),
+                                             16, 0, 0);
+        }
+        if (lane < 8)
+            __builtin_amdgcn_global_load_lds((gptr_t)(a.auxp + row0 + 8 * wave + lane),
+                                             (lptr_t)(auxr + (stage % kAuxRing) * BF_BN + 8 * wave), 4, 0, 0);
+    };
+
+    // this lane's QG queries: fragments of both halves; lane (l31, h) holds elements 16*kc + 8*h + {0..7}
+    bf16x8 qh[QG][8], ql[QG][8];
+    float thr[QG];
+    int cnt[QG];
+    uint32_t* lp[QG];
+    float t8[SAMPLE ? QG : 1][8];
+#pragma unroll
+    for (int g = 0; g < QG; ++g) {
+        const int qidx = (qt * 8 + wave) * (32 * QG) + g * 32 + l31;
+#pragma unroll
+        for (int kc = 0; kc < 8; ++kc) {
+            qh[g][kc] = *reinterpret_cast<const bf16x8*>(a.q_hi + (size_t)qidx * 128 + 16 * kc + 8 * h);
+            ql[g][kc] = *reinterpret_cast<const bf16x8*>(a.q_lo + (size_t)qidx * 128 + 16 * kc + 8 * h);
+        }
+        cnt[g] = 0;
+        if constexpr (SAMPLE) {
+            thr[g] = -INFINITY;
+            lp[g] = nullptr;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) t8[g][i] = -INFINITY;
+        } else {
+            thr[g] = a.thr[qidx];
+            lp[g] = a.list + (((size_t)qidx * a.nsplit + split) * 2 + h) * a.caph;
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): retire the query loads before any DMA is counted
+
+    for (int t = 0; t < kRing - 1 && t < nstages; ++t) issue_tile(t);
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+
+    // scores of one 32-row block (16 per lane) of query group g against the lane's threshold
+    auto examine = [&](const f32x16& c, int g, const float* ax, int row0) __attribute__((always_inline)) {
+        float sc[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            if constexpr (MODE == SC_COS) sc[i] = c[i] * ax[(i & 3) + 8 * (i >> 2)];
+            else sc[i] = c[i];
+        }
+        float m = fmaxf(fmaxf(sc[0], sc[1]), sc[2]);
+#pragma unroll
+        for (int i = 3; i + 1 < 16; i += 2) m = fmaxf(fmaxf(m, sc[i]), sc[i + 1]);
+        m = fmaxf(m, sc[15]);
+        if constexpr (SAMPLE) {
+            if (__any(m > thr[g])) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    float v = sc[i];
+                    if (v > t8[g][7] && row0 + acc_row(i, h) < a.n) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const float hi = fmaxf(t8[g][j], v);
+                            v = fminf(t8[g][j], v);
+                            t8[g][j] = hi;
+                        }
+                    }
+                }
+                thr[g] = t8[g][7];
+            }
+        } else if (__any(m >= thr[g])) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int pos = row0 + acc_row(i, h);
+                if (sc[i] >= thr[g] && pos < a.n) {
+                    if (cnt[g] < a.caph) lp[g][cnt[g]] = (uint32_t)pos;
+                    cnt[g]++;
+                }
+            }
+        }
+    };
+
+    for (int t = 0; t < nstages; ++t) {
+        const char* th_ = ring + (t % kRing) * kStageBytes;   // hi tile; lo tile kHalfBytes behind
+        const float* axs = auxr + (t % kAuxRing) * BF_BN + 4 * h;
+        const int row0 = r_begin + t * stage_rows;
+        // the slot of stage t+3 held stage t-1: every wave passed the barrier that ended stage t-1 after its reads
+        if (t + kRing - 1 < nstages) issue_tile(t + kRing - 1);
+        f32x16 prev[QG];
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+            const int row = blk * 32 + l31;
+            const char* rp = th_ + row * 256;
+            const int rs = row & 15;
+            f32x16 acc[QG];
+            if constexpr (MODE == SC_L2) {
+                // accumulators start from -0.5|b|^2 of their rows: register 4j+i of half h = row 8j + 4h + i of the block
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(axs + blk * 32 + 8 * j);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                        for (int g = 0; g < QG; ++g) acc[g][4 * j + i] = v[i];
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int g = 0; g < QG; ++g) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) acc[g][i] = 0.f;
+                }
+            }
+            // fragment reads run two K-steps ahead of the MFMAs that use them
+            bf16x8 fh[3], fl[3];
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                fh[p] = *reinterpret_cast<const bf16x8*>(rp + (((p * 2 + h) ^ rs) * 16));
+                fl[p] = *reinterpret_cast<const bf16x8*>(rp + kHalfBytes + (((p * 2 + h) ^ rs) * 16));
+            }
+#pragma unroll
+            for (int kc = 0; kc < 8; ++kc) {
+                if (kc + 2 < 8) {
+                    fh[(kc + 2) % 3] = *reinterpret_cast<const bf16x8*>(rp + ((((kc + 2) * 2 + h) ^ rs) * 16));
+                    fl[(kc + 2) % 3] = *reinterpret_cast<const bf16x8*>(rp + kHalfBytes + ((((kc + 2) * 2 + h) ^ rs) * 16));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int g = 0; g < QG; ++g) {
+                    acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[kc % 3], qh[g][kc], acc[g], 0, 0, 0);
+                    acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl[kc % 3], qh[g][kc], acc[g], 0, 0, 0);
+                    acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[kc % 3], ql[g][kc], acc[g], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (blk == 1 && kc < QG) examine(prev[kc], kc, axs, row0);  // block 0 of this stage, under block 1's MFMAs
+            }
+#pragma unroll
+            for (int g = 0; g < QG; ++g) prev[g] = acc[g];
+        }
+#pragma unroll
+        for (int g = 0; g < QG; ++g) examine(prev[g], g, axs + 32, row0 + 32);
+        // stage t+1 must have landed; stages t+2, t+3 (5 DMA instructions per wave each) may stay in flight
+        if (t + kRing - 1 < nstages) asm volatile("s_waitcnt vmcnt(10)\n\ts_barrier" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+#pragma unroll
+    for (int g = 0; g < QG; ++g) {
+        const int qidx = (qt * 8 + wave) * (32 * QG) + g * 32 + l31;
+        if constexpr (SAMPLE) {
+            float* o = a.top8 + (((size_t)qidx * a.nsplit + split) * 2 + h) * 8;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o[i] = t8[g][i];
+        } else {
+            a.list_cnt[((size_t)qidx * a.nsplit + split) * 2 + h] = cnt[g];
+        }
+    }
+}
+
+// rows -> two bf16 tiles (hi = bf16(x), lo = bf16(x - hi)), padded to 128 columns and n_pad rows; auxp = aux with the
+// pad rows' value
+__global__ void split_bf16_kernel(const float* src, int rows, int rows_pad, int ld, int dim, __bf16* hi, __bf16* lo,
+                                  const float* aux, float aux_pad, float* auxp) {
+    const size_t total = (size_t)rows_pad * 128;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = i >> 7;
+        const int c = (int)(i & 127);
+        const float v = (r < (size_t)rows && c < dim) ? src[r * ld + c] : 0.f;
+        const __bf16 hh = (__bf16)v;
+        hi[i] = hh;
+        lo[i] = (__bf16)(v - (float)hh);
+        if (c == 0 && auxp) auxp[r] = r < (size_t)rows ? (aux ? aux[r] : 0.f) : aux_pad;
+    }
+}
+
+// r-th best value of the sample -> threshold per query (float scores); one wave per query
+__global__ __launch_bounds__(64) void bf_f32_threshold_kernel(const float* top8, int nlists, int r, int nq, float* thr) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    u64* keys = reinterpret_cast<u64*>(smem);
+    const int q = blockIdx.x, lane = threadIdx.x;
+    if (q >= nq) {  // padding queries: nothing passes
+        if (lane == 0) thr[q] = INFINITY;
+        return;
+    }
+    const int total = nlists * 8;
+    const int P = next_pow2(total < 2 ? 2 : total);
+    for (int i = lane; i < P; i += 64) keys[i] = i < total ? (u64)f32_ord(top8[(size_t)q * total + i]) : 0ull;
+    __builtin_amdgcn_wave_barrier();
+    wave_bitonic_u64(keys, P, lane, /*descending=*/true);
+    if (lane == 0) thr[q] = total >= r ? ord_f32((uint32_t)keys[r - 1]) : -INFINITY;
+}
+
+// exact distances (the reference formula on the ORIGINAL rows) of the listed rows, (distance, position) order, top k;
+// verification of the threshold bet like bf_rerank_u8_list_kernel
+struct RerankListF32Args {
+    const float* base;        // original rows [n][ldb]
+    const float* queries;     // original padded queries [qpad][ldb]
+    const uint32_t* list;
+    const int* list_cnt;
+    const int32_t* ext_ids;
+    int32_t* out_ids;
+    float* out_dists;
+    int32_t* out_cnt;
+    int* tile_fail;
+    int n, k, nsplit, caph, p2max, fail_queries, space, dim, ldb;
+};
+
+__global__ __launch_bounds__(256) void bf_rerank_f32_list_kernel(RerankListF32Args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    u64* keys = reinterpret_cast<u64*>(smem);              // [p2max]
+    int* offs = reinterpret_cast<int*>(keys + a.p2max);    // [2 * nsplit + 1]
+    __shared__ int s_over;
+    const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nl = 2 * a.nsplit;
+    if (tid == 0) {
+        int o = 0, over = 0;
+        for (int s = 0; s < nl; ++s) {
+            offs[s] = o;
+            const int c = a.list_cnt[(size_t)q * nl + s];
+            over |= c > a.caph;
+            o += c < a.caph ? c : a.caph;
+        }
+        offs[nl] = o;
+        s_over = over;
+    }
+    __syncthreads();
+    const int total = offs[nl];
+    const int need = a.k < a.n ? a.k : a.n;
+    // the adaptive kernel keeps k' = k + max(4, k/8) per split: ask for the same slack over the whole base here
+    const int want = need + (a.k / 8 > 4 ? a.k / 8 : 4) < a.n ? need + (a.k / 8 > 4 ? a.k / 8 : 4) : a.n;
+    if (s_over || total < want || total > a.p2max) {
+        if (tid == 0) atomicOr(&a.tile_fail[q / a.fail_queries], 1);
+        return;
+    }
+    for (int idx = tid; idx < nl * a.caph; idx += blockDim.x) {
+        const int s = idx / a.caph, i = idx - s * a.caph;
+        if (i < offs[s + 1] - offs[s]) keys[offs[s] + i] = (u64)a.list[((size_t)q * nl + s) * a.caph + i];
+    }
+    __syncthreads();
+    const int P = next_pow2(total < 2 ? 2 : total);
+    const float* qq = a.queries + (size_t)q * a.ldb;
+    for (int j0 = wave * 4; j0 < total; j0 += 16) {
+        uint32_t pos[4];
+        const float* rows[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int j = j0 + r < total ? j0 + r : total - 1;
+            pos[r] = (uint32_t)keys[j];
+            rows[r] = a.base + (size_t)pos[r] * a.ldb;
+        }
+        float d[4];
+        wave_exact_distance_f32_x4(a.space, rows, qq, a.dim, lane, d);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (lane == 0 && j0 + r < total) keys[j0 + r] = ((u64)f32_ord(d[r]) << 32) | pos[r];
+    }
+    for (int i = total + tid; i < P; i += blockDim.x) keys[i] = ~0ull;
+    __syncthreads();
+    block_bitonic_u64_asc(keys, P, tid, blockDim.x);
+    const int found = total < a.k ? total : a.k;
+    for (int i = tid; i < a.k; i += blockDim.x) {
+        int32_t id = -1;
+        float d = INFINITY;
+        if (i < found) {
+            const u64 key = keys[i];
+            const uint32_t pos = (uint32_t)key;
+            id = a.ext_ids ? a.ext_ids[pos] : (int32_t)pos;
+            d = ord_f32((uint32_t)(key >> 32));
+        }
+        a.out_ids[(size_t)q * a.k + i] = id;
+        a.out_dists[(size_t)q * a.k + i] = d;
+    }
+    if (tid == 0 && a.out_cnt) a.out_cnt[q] = found;
+}
+
+// ---------------------------------------------------------------------------------------
 // Re-rank: one workgroup per query.  Exact reference-formula distance of every survivor,
 // 64-bit keys (distance, position) sorted ascending, first k emitted.
 // ---------------------------------------------------------------------------------------
@@ -1689,11 +2029,19 @@ static BfArgs make_args(const BfPlan& p, const float* base, const float* aux, co
 hipError_t launch_bf_select_f32(const BfPlan& p, int space, const float* base, const float* aux,
                                 const float* queries_padded, const float* qaux_cosc, unsigned long long* cand,
                                 int* cand_cnt, hipStream_t s) {
+    return launch_bf_select_f32_ex(p, space, base, aux, queries_padded, qaux_cosc, cand, cand_cnt, nullptr, 1, s);
+}
+
+hipError_t launch_bf_select_f32_ex(const BfPlan& p, int space, const float* base, const float* aux,
+                                   const float* queries_padded, const float* qaux_cosc, unsigned long long* cand,
+                                   int* cand_cnt, const int* tile_fail, int fail_group, hipStream_t s) {
     // per-query shared thresholds live behind the survivor counts; cleared for every batch
     uint32_t* gthr = reinterpret_cast<uint32_t*>(cand_cnt + (size_t)p.qpad * p.nsplit);
     hipError_t me = hipMemsetAsync(gthr, 0, ((size_t)p.qpad + (size_t)p.qpad * p.nsplit) * 4, s);
     if (me != hipSuccess) return me;
     BfArgs a = make_args(p, base, aux, queries_padded, cand, cand_cnt, gthr);
+    a.tile_fail = tile_fail;
+    a.fail_group = fail_group;
     switch (space) {
         case SP_L2: return launch_select_mode<BF_L2>(p, a, s);
         case SP_NEGDOT: return launch_select_mode<BF_DOT>(p, a, s);
@@ -1935,6 +2283,165 @@ hipError_t launch_bf_u8_fast(const BfU8Fast& f, int n, int nq, int k, const uint
     if (e != hipSuccess) return e;
     return launch_bf_rerank_ex(f.fallback, SP_L2SQR_SIFT, 128, k, base_u8, queries_padded, cand_fb, cnt_fb, ext_ids, out_ids,
                                out_dists, out_cnt, tile_fail, BF_TQ * f.qg, s);
+}
+
+// ---- f32 fast path (see bf_scan_f32_kernel) -----------------------------------------------------------------
+BfF32Fast bf_f32_fast_plan(int n, int dim, int nq, int k, int space, bool cosine_centred) {
+    BfF32Fast f{};
+    const bool space_ok = space == SP_L2 || space == SP_NEGDOT || ((space == SP_COSINE || space == SP_ANGULAR) && !cosine_centred);
+    f.use = space_ok && dim <= 128 && n >= 131072 && nq >= 256 && k <= 128;
+    if (const char* e = getenv("NMSLIB_GPU_F32_FAST")) f.use = f.use && atoi(e) != 0;
+    if (!f.use) return f;
+    f.mode = space == SP_L2 ? 0 : (space == SP_NEGDOT ? 1 : 2);
+    // query groups of 32 per wave: a workgroup (8 waves) serves 256 * qg queries.  Two groups halve the L2 -> LDS
+    // stream and the fragment reads per MFMA but need 256+ VGPRs (both bf16 halves of 64 queries resident): the
+    // compiler spills and the kernel gets slower (0.75 vs 0.68 ms at C2), so one group is the default
+    f.qg = 1;
+    if (const char* e = getenv("NMSLIB_GPU_F32_QG")) f.qg = atoi(e) == 2 ? 2 : 1;
+    const int tq = 256 * f.qg;
+    f.qpad = (nq + tq - 1) / tq * tq;
+    f.nqt = f.qpad / tq;
+    f.stride = 8;
+    // float spaces keep a slack of k' - k rows for the re-rank (the selection score is not the reference formula):
+    // aim the threshold at k' = k + max(4, k/8)
+    const int kp = k + (k / 8 > 4 ? k / 8 : 4);
+    const double kf = (double)kp / f.stride;
+    f.r = (int)(1.6 * kf + 3.0 * sqrt(kf) + 3.0 + 0.999);
+    const int tiles_all = (n + BF_BN - 1) / BF_BN;
+    int ns = (256 + f.nqt - 1) / f.nqt;
+    if (ns > tiles_all / 16) ns = tiles_all / 16;
+    if (ns > 256) ns = 256;
+    ns = (ns + 7) / 8 * 8;
+    if (ns < 8) ns = 8;
+    f.nsplit = ns;
+    f.tps = (tiles_all + ns - 1) / ns;
+    const double mean_half = (double)f.r * f.stride / (2.0 * ns);
+    int caph = 8;
+    while (caph < 4.0 * mean_half + 8.0) caph <<= 1;
+    f.caph = caph;
+    f.p2max = host_next_pow2(2 * ns * caph);
+    f.lds_scan = 4 * 2 * BF_BN * 256 + 8 * BF_BN * 4 + 64;
+    f.lds_rerank = (size_t)f.p2max * 8 + (2 * (size_t)ns + 1) * 4 + 16;
+    const int stiles = (tiles_all + f.stride - 1) / f.stride;
+    const int s_nqt = f.qpad / 256;
+    int nss = (256 + s_nqt - 1) / s_nqt;
+    if (nss > stiles / 16) nss = stiles / 16;
+    if (nss > 64) nss = 64;
+    nss = (nss + 7) / 8 * 8;
+    if (nss < 8) nss = 8;
+    f.s_nsplit = nss;
+    f.s_tps = (stiles + nss - 1) / nss;
+    f.lds_thr = (size_t)host_next_pow2(nss * 2 * 8) * 8 + 16;
+    f.fallback = bf_make_plan(n, dim, nq, k, false, tq);
+    return f;
+}
+
+hipError_t launch_split_bf16(const float* src, int rows, int rows_pad, int ld, int dim, void* hi, void* lo,
+                             const float* aux, float aux_pad, float* auxp, hipStream_t s) {
+    const size_t total = (size_t)rows_pad * 128;
+    if (total == 0) return hipSuccess;
+    size_t grid = (total + 255) / 256;
+    if (grid > 16384) grid = 16384;
+    hipLaunchKernelGGL(split_bf16_kernel, dim3((unsigned)grid), dim3(256), 0, s, src, rows, rows_pad, ld, dim,
+                       static_cast<__bf16*>(hi), static_cast<__bf16*>(lo), aux, aux_pad, auxp);
+    return hipGetLastError();
+}
+
+template <int MODE, bool SAMPLE, int QG>
+static hipError_t launch_scan_f32_one(const BfScanF32Args& a, int grid, size_t lds, hipStream_t s) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bf_scan_f32_kernel<MODE, SAMPLE, QG>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((bf_scan_f32_kernel<MODE, SAMPLE, QG>), dim3(grid), dim3(512), lds, s, a);
+    return hipGetLastError();
+}
+template <int MODE>
+static hipError_t launch_scan_f32_mode(const BfScanF32Args& a, bool sample, int qg, int grid, size_t lds, hipStream_t s) {
+    if (sample) return launch_scan_f32_one<MODE, true, 1>(a, grid, lds, s);   // (the sample pass always with one group)
+    if (qg == 2) return launch_scan_f32_one<MODE, false, 2>(a, grid, lds, s);
+    return launch_scan_f32_one<MODE, false, 1>(a, grid, lds, s);
+}
+
+hipError_t launch_bf_f32_fast(const BfF32Fast& f, int space, int n, int dim, int ldb, int nq, int k, const float* base_orig,
+                              const float* sel_rows, const float* aux, const void* base_hi, const void* base_lo,
+                              const float* auxp, const float* queries_orig, const float* queries_sel, void* q_hi,
+                              void* q_lo, float* top8, unsigned long long* cand_fb, int* cnt_fb, float* thr,
+                              uint32_t* list, int* list_cnt, int* tile_fail, const int32_t* ext_ids, int32_t* out_ids,
+                              float* out_dists, int32_t* out_cnt, hipEvent_t scan_begin, hipEvent_t scan_end,
+                              hipStream_t s) {
+    hipError_t e = launch_split_bf16(queries_sel, f.qpad, f.qpad, ldb, dim, q_hi, q_lo, nullptr, 0.f, nullptr, s);
+    if (e != hipSuccess) return e;
+    auto scan = [&](const BfScanF32Args& sa, bool sample, int grid) -> hipError_t {
+        if (f.mode == 0) return launch_scan_f32_mode<SC_L2>(sa, sample, f.qg, grid, f.lds_scan, s);
+        if (f.mode == 1) return launch_scan_f32_mode<SC_DOT>(sa, sample, f.qg, grid, f.lds_scan, s);
+        return launch_scan_f32_mode<SC_COS>(sa, sample, f.qg, grid, f.lds_scan, s);
+    };
+    BfScanF32Args a{};
+    a.base_hi = static_cast<const __bf16*>(base_hi);
+    a.base_lo = static_cast<const __bf16*>(base_lo);
+    a.auxp = auxp;
+    a.q_hi = static_cast<const __bf16*>(q_hi);
+    a.q_lo = static_cast<const __bf16*>(q_lo);
+    a.n = n;
+    a.nqt = f.nqt;
+    // 1. sample pass + thresholds
+    BfScanF32Args sa = a;
+    sa.nqt = f.qpad / 256;
+    sa.nsplit = f.s_nsplit;
+    sa.tps = f.s_tps;
+    sa.tile_stride = f.stride;
+    sa.top8 = top8;
+    e = scan(sa, true, 8 * sa.nqt * (f.s_nsplit / 8));
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(bf_f32_threshold_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)f.lds_thr);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(bf_f32_threshold_kernel, dim3(f.qpad), dim3(64), f.lds_thr, s, top8, 2 * f.s_nsplit, f.r, nq, thr);
+    e = hipMemsetAsync(tile_fail, 0, (size_t)f.nqt * 4, s);
+    if (e != hipSuccess) return e;
+    // 2. scan with fixed thresholds
+    a.thr = thr;
+    a.list = list;
+    a.list_cnt = list_cnt;
+    a.nsplit = f.nsplit;
+    a.tps = f.tps;
+    a.caph = f.caph;
+    a.tile_stride = 1;
+    if (scan_begin) (void)hipEventRecord(scan_begin, s);
+    e = scan(a, false, 8 * f.nqt * (f.nsplit / 8));
+    if (scan_end) (void)hipEventRecord(scan_end, s);
+    if (e != hipSuccess) return e;
+    // 3. exact re-rank (reference formula, original rows) + verification
+    RerankListF32Args r{};
+    r.base = base_orig;
+    r.queries = queries_orig;
+    r.list = list;
+    r.list_cnt = list_cnt;
+    r.ext_ids = ext_ids;
+    r.out_ids = out_ids;
+    r.out_dists = out_dists;
+    r.out_cnt = out_cnt;
+    r.tile_fail = tile_fail;
+    r.n = n;
+    r.k = k;
+    r.nsplit = f.nsplit;
+    r.caph = f.caph;
+    r.p2max = f.p2max;
+    r.fail_queries = 256 * f.qg;
+    r.space = space;
+    r.dim = dim;
+    r.ldb = ldb;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(bf_rerank_f32_list_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)f.lds_rerank);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(bf_rerank_f32_list_kernel, dim3(nq), dim3(256), f.lds_rerank, s, r);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    // 4. fallback: the adaptive f32 kernel + its re-rank for flagged 256-query groups (= 2 of its 128-query tiles)
+    e = launch_bf_select_f32_ex(f.fallback, space, sel_rows, aux, queries_sel, nullptr, cand_fb, cnt_fb, tile_fail, 2 * f.qg, s);
+    if (e != hipSuccess) return e;
+    return launch_bf_rerank_ex(f.fallback, space, dim, k, base_orig, queries_orig, cand_fb, cnt_fb, ext_ids, out_ids,
+                               out_dists, out_cnt, tile_fail, 256 * f.qg, s);
 }
 
 hipError_t launch_row_aux_f32(const float* base, int n, int ldb, int dim, int space, float* aux,

