@@ -776,6 +776,12 @@ void Engine::finalize() {
                                             space_ == SP_NEGDOT ? nullptr : d_aux_.as<float>(), pad, d_auxp_.as<float>(),
                                             stream_),
                           "split rows");
+                // largest row norm of the selection rows: the error bound of the split-bf16 score (re-rank proof)
+                DevBuf d_bm;
+                d_bm.ensure(16);
+                hip_check(launch_row_maxnorm(sel_rows, (int)n, ldb_, (int)dim_, d_bm.as<float>(), stream_), "row norms");
+                hip_check(hipMemcpyAsync(&bmax_, d_bm.ptr(), 4, hipMemcpyDeviceToHost, stream_), "bmax");
+                hip_check(hipStreamSynchronize(stream_), "row norms");
                 have_bf16_ = true;
             }
         }
@@ -1016,7 +1022,7 @@ void Engine::knn_brute(const void* d_queries, size_t nq, size_t k, int32_t* d_id
             }
             hip_check(launch_bf_f32_fast(f, space_, (int)d_n_, dim_eff, ldb, (int)nq, (int)k, d_rows_.as<float>(),
                                          centred_ ? d_rows_sel_.as<float>() : d_rows_.as<float>(), d_aux_.as<float>(),
-                                         d_bf_hi_.ptr(), d_bf_lo_.ptr(), d_auxp_.as<float>(), ws_qpad_.as<float>(), qsel, qh, ql,
+                                         d_bf_hi_.ptr(), d_bf_lo_.ptr(), d_auxp_.as<float>(), bmax_, ws_qpad_.as<float>(), qsel, qh, ql,
                                          ws_u8_cand_.as<float>(), ws_cand_.as<unsigned long long>(), ws_cnt_.as<int>(), thr,
                                          ws_u8_list_.as<uint32_t>(), ws_u8_listcnt_.as<int>(), tile_fail,
                                          d_ids_.as<int32_t>(), d_ids, d_dists, d_cnt, eb, ee, stream),

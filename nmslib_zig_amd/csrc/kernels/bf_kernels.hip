@@ -1137,23 +1137,24 @@ __global__ __launch_bounds__(256, 2) void bf_scan_u8_kernel(BfScanArgs a) {
 
 // r-th best value of the sample (union of the lanes' top-8 lists) -> scan threshold of each query; one wave per query.
 // Any value works as a threshold -- the re-rank verifies the outcome -- this one makes ~r * stride rows pass.
-__global__ __launch_bounds__(64) void bf_u8_threshold_kernel(const int* top8, int nlists, int r, int nq, int* thr) {
+__global__ __launch_bounds__(256) void bf_u8_threshold_kernel(const int* top8, int nlists, int r, int nq, int* thr) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     u64* keys = reinterpret_cast<u64*>(smem);
-    const int q = blockIdx.x, lane = threadIdx.x;
+    const int q = blockIdx.x, tid = threadIdx.x;
     constexpr int kPassAll = -(1 << 28);  // below every real value, above the pad rows' -2^29
     if (q >= nq) {                        // padding queries: nothing may pass
-        if (lane == 0) thr[q] = 0x7FFFFFFF;
+        if (tid == 0) thr[q] = 0x7FFFFFFF;
         return;
     }
     const int total = nlists * 8;
     const int P = next_pow2(total < 2 ? 2 : total);
-    for (int i = lane; i < P; i += 64) keys[i] = i < total ? (u64)i32_ord(top8[(size_t)q * total + i]) : 0ull;
-    __builtin_amdgcn_wave_barrier();
-    wave_bitonic_u64(keys, P, lane, /*descending=*/true);
-    if (lane == 0) {
+    // ascending sort of the complemented order keys = descending by value
+    for (int i = tid; i < P; i += blockDim.x) keys[i] = i < total ? (u64)(~i32_ord(top8[(size_t)q * total + i])) : ~0ull;
+    __syncthreads();
+    block_bitonic_u64_asc(keys, P, tid, blockDim.x);
+    if (tid == 0) {
         int t = kPassAll;
-        if (total >= r) t = max(kPassAll, ord_i32((uint32_t)keys[r - 1]));
+        if (total >= r) t = max(kPassAll, ord_i32(~(uint32_t)keys[r - 1]));
         thr[q] = t;
     }
 }
@@ -1353,23 +1354,24 @@ __global__ __launch_bounds__(512, 2) void bf_scan_f32_kernel(BfScanF32Args a) {
     for (int t = 0; t < kRing - 1 && t < nstages; ++t) issue_tile(t);
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
 
-    // scores of one 32-row block (16 per lane) of query group g against the lane's threshold
-    auto examine = [&](const f32x16& c, int g, const float* ax, int row0) __attribute__((always_inline)) {
-        float sc[16];
+    // byte offset of this lane's fragment of K-step kc inside its row (row & 15 is the same for both blocks: 32 = 0 mod 16)
+    int foff[8];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            if constexpr (MODE == SC_COS) sc[i] = c[i] * ax[(i & 3) + 8 * (i >> 2)];
-            else sc[i] = c[i];
-        }
-        float m = fmaxf(fmaxf(sc[0], sc[1]), sc[2]);
-#pragma unroll
-        for (int i = 3; i + 1 < 16; i += 2) m = fmaxf(fmaxf(m, sc[i]), sc[i + 1]);
-        m = fmaxf(m, sc[15]);
+    for (int kc = 0; kc < 8; ++kc) foff[kc] = l31 * 256 + (((kc * 2 + h) ^ (l31 & 15)) * 16);
+
+    // Score check of one finished 32-row block (16 scores per lane and query group), spread over the MFMA stream of the
+    // NEXT block: two elements of the running maximum per K-step (a clump of ~40 VALU instructions between two MFMAs
+    // holds the matrix pipe up; two per gap ride in its shadow), then one compare; the element-wise path only on a hit.
+    auto score_of = [&](const f32x16& c, int i, const float* ax) __attribute__((always_inline)) -> float {
+        if constexpr (MODE == SC_COS) return c[i] * ax[(i & 3) + 8 * (i >> 2)];
+        else return c[i];
+    };
+    auto finish_check = [&](float m, const f32x16& c, int g, const float* ax, int row0) __attribute__((always_inline)) {
         if constexpr (SAMPLE) {
             if (__any(m > thr[g])) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
-                    float v = sc[i];
+                    float v = score_of(c, i, ax);
                     if (v > t8[g][7] && row0 + acc_row(i, h) < a.n) {
 #pragma unroll
                         for (int j = 0; j < 8; ++j) {
@@ -1385,7 +1387,7 @@ __global__ __launch_bounds__(512, 2) void bf_scan_f32_kernel(BfScanF32Args a) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int pos = row0 + acc_row(i, h);
-                if (sc[i] >= thr[g] && pos < a.n) {
+                if (score_of(c, i, ax) >= thr[g] && pos < a.n) {
                     if (cnt[g] < a.caph) lp[g][cnt[g]] = (uint32_t)pos;
                     cnt[g]++;
                 }
@@ -1393,18 +1395,19 @@ __global__ __launch_bounds__(512, 2) void bf_scan_f32_kernel(BfScanF32Args a) {
         }
     };
 
+    f32x16 pv[QG];            // scores of the previous block (possibly of the previous stage), not yet checked
+    const float* pv_ax = auxr;
+    int pv_row0 = 0;
+    bool have_pv = false;
     for (int t = 0; t < nstages; ++t) {
         const char* th_ = ring + (t % kRing) * kStageBytes;   // hi tile; lo tile kHalfBytes behind
         const float* axs = auxr + (t % kAuxRing) * BF_BN + 4 * h;
         const int row0 = r_begin + t * stage_rows;
         // the slot of stage t+3 held stage t-1: every wave passed the barrier that ended stage t-1 after its reads
         if (t + kRing - 1 < nstages) issue_tile(t + kRing - 1);
-        f32x16 prev[QG];
 #pragma unroll
         for (int blk = 0; blk < 2; ++blk) {
-            const int row = blk * 32 + l31;
-            const char* rp = th_ + row * 256;
-            const int rs = row & 15;
+            const char* rp = th_ + blk * 32 * 256;
             f32x16 acc[QG];
             if constexpr (MODE == SC_L2) {
                 // accumulators start from -0.5|b|^2 of their rows: register 4j+i of half h = row 8j + 4h + i of the block
@@ -1428,14 +1431,17 @@ __global__ __launch_bounds__(512, 2) void bf_scan_f32_kernel(BfScanF32Args a) {
             bf16x8 fh[3], fl[3];
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
-                fh[p] = *reinterpret_cast<const bf16x8*>(rp + (((p * 2 + h) ^ rs) * 16));
-                fl[p] = *reinterpret_cast<const bf16x8*>(rp + kHalfBytes + (((p * 2 + h) ^ rs) * 16));
+                fh[p] = *reinterpret_cast<const bf16x8*>(rp + foff[p]);
+                fl[p] = *reinterpret_cast<const bf16x8*>(rp + kHalfBytes + foff[p]);
             }
+            float mrun[QG];
+#pragma unroll
+            for (int g = 0; g < QG; ++g) mrun[g] = -INFINITY;
 #pragma unroll
             for (int kc = 0; kc < 8; ++kc) {
                 if (kc + 2 < 8) {
-                    fh[(kc + 2) % 3] = *reinterpret_cast<const bf16x8*>(rp + ((((kc + 2) * 2 + h) ^ rs) * 16));
-                    fl[(kc + 2) % 3] = *reinterpret_cast<const bf16x8*>(rp + kHalfBytes + ((((kc + 2) * 2 + h) ^ rs) * 16));
+                    fh[(kc + 2) % 3] = *reinterpret_cast<const bf16x8*>(rp + foff[kc + 2]);
+                    fl[(kc + 2) % 3] = *reinterpret_cast<const bf16x8*>(rp + kHalfBytes + foff[kc + 2]);
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -1444,17 +1450,35 @@ __global__ __launch_bounds__(512, 2) void bf_scan_f32_kernel(BfScanF32Args a) {
                     acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl[kc % 3], qh[g][kc], acc[g], 0, 0, 0);
                     acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[kc % 3], ql[g][kc], acc[g], 0, 0, 0);
                 }
+                if (have_pv) {
+#pragma unroll
+                    for (int g = 0; g < QG; ++g)
+                        mrun[g] = fmaxf(fmaxf(mrun[g], score_of(pv[g], 2 * kc, pv_ax)), score_of(pv[g], 2 * kc + 1, pv_ax));
+                }
                 __builtin_amdgcn_sched_barrier(0);
-                if (blk == 1 && kc < QG) examine(prev[kc], kc, axs, row0);  // block 0 of this stage, under block 1's MFMAs
+            }
+            if (have_pv) {
+#pragma unroll
+                for (int g = 0; g < QG; ++g) finish_check(mrun[g], pv[g], g, pv_ax, pv_row0);
             }
 #pragma unroll
-            for (int g = 0; g < QG; ++g) prev[g] = acc[g];
+            for (int g = 0; g < QG; ++g) pv[g] = acc[g];
+            pv_ax = axs + blk * 32;
+            pv_row0 = row0 + blk * 32;
+            have_pv = true;
         }
-#pragma unroll
-        for (int g = 0; g < QG; ++g) examine(prev[g], g, axs + 32, row0 + 32);
         // stage t+1 must have landed; stages t+2, t+3 (5 DMA instructions per wave each) may stay in flight
         if (t + kRing - 1 < nstages) asm volatile("s_waitcnt vmcnt(10)\n\ts_barrier" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    if (have_pv) {  // the last block
+#pragma unroll
+        for (int g = 0; g < QG; ++g) {
+            float m = -INFINITY;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) m = fmaxf(m, score_of(pv[g], i, pv_ax));
+            finish_check(m, pv[g], g, pv_ax, pv_row0);
+        }
     }
 #pragma unroll
     for (int g = 0; g < QG; ++g) {
@@ -1486,20 +1510,20 @@ __global__ void split_bf16_kernel(const float* src, int rows, int rows_pad, int 
 }
 
 // r-th best value of the sample -> threshold per query (float scores); one wave per query
-__global__ __launch_bounds__(64) void bf_f32_threshold_kernel(const float* top8, int nlists, int r, int nq, float* thr) {
+__global__ __launch_bounds__(256) void bf_f32_threshold_kernel(const float* top8, int nlists, int r, int nq, float* thr) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     u64* keys = reinterpret_cast<u64*>(smem);
-    const int q = blockIdx.x, lane = threadIdx.x;
+    const int q = blockIdx.x, tid = threadIdx.x;
     if (q >= nq) {  // padding queries: nothing passes
-        if (lane == 0) thr[q] = INFINITY;
+        if (tid == 0) thr[q] = INFINITY;
         return;
     }
     const int total = nlists * 8;
     const int P = next_pow2(total < 2 ? 2 : total);
-    for (int i = lane; i < P; i += 64) keys[i] = i < total ? (u64)f32_ord(top8[(size_t)q * total + i]) : 0ull;
-    __builtin_amdgcn_wave_barrier();
-    wave_bitonic_u64(keys, P, lane, /*descending=*/true);
-    if (lane == 0) thr[q] = total >= r ? ord_f32((uint32_t)keys[r - 1]) : -INFINITY;
+    for (int i = tid; i < P; i += blockDim.x) keys[i] = i < total ? (u64)(~f32_ord(top8[(size_t)q * total + i])) : ~0ull;
+    __syncthreads();
+    block_bitonic_u64_asc(keys, P, tid, blockDim.x);
+    if (tid == 0) thr[q] = total >= r ? ord_f32(~(uint32_t)keys[r - 1]) : -INFINITY;
 }
 
 // exact distances (the reference formula on the ORIGINAL rows) of the listed rows, (distance, position) order, top k;
@@ -1515,6 +1539,9 @@ struct RerankListF32Args {
     int32_t* out_cnt;
     int* tile_fail;
     int n, k, nsplit, caph, p2max, fail_queries, space, dim, ldb;
+    const float* queries_sel;  // the queries the selection saw (centred for l2 on un-centred data)
+    const float* thr;          // [qpad] selection thresholds (score units)
+    float bmax;                // largest row norm of the selection rows
 };
 
 __global__ __launch_bounds__(256) void bf_rerank_f32_list_kernel(RerankListF32Args a) {
@@ -1571,6 +1598,40 @@ __global__ __launch_bounds__(256) void bf_rerank_f32_list_kernel(RerankListF32Ar
     __syncthreads();
     block_bitonic_u64_asc(keys, P, tid, blockDim.x);
     const int found = total < a.k ? total : a.k;
+    // PROOF that no unlisted row belongs to the top k.  The selection score of every row carries an error of at most
+    // E = 2^-15 |q||b| (split-bf16 products: the dropped lo.lo term and the two split residues are each <= 2^-18 per
+    // product, f32 accumulation ~2^-19; a factor 2 of margin).  Unlisted rows scored below the threshold T, so their
+    // exact score is below T + E; if the exact score S_k of the k-th result is at least that, every unlisted row is
+    // strictly farther than the k-th result.  Otherwise the adaptive kernel redoes the query's tile group.
+    if (total < a.n) {
+        __shared__ float s_qn2;
+        if (tid < 64) {
+            const float* qs = a.queries_sel + (size_t)q * a.ldb;
+            float ss = 0.f;
+            for (int d = tid; d < a.dim; d += 64) ss = fmaf(qs[d], qs[d], ss);
+            ss = wave_sum(ss);
+            if (tid == 0) s_qn2 = ss;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            const float qn2 = s_qn2, qn = sqrtf(qn2);
+            const float dk = ord_f32((uint32_t)(keys[found - 1] >> 32));
+            float sk, e;
+            if (a.space == SP_L2) {
+                sk = 0.5f * (qn2 - dk * dk);
+                e = 3.0518e-5f * qn * a.bmax;
+            } else if (a.space == SP_NEGDOT) {
+                sk = -dk;
+                e = 3.0518e-5f * qn * a.bmax;
+            } else {  // cosine / angular: score = q.b / |b| = similarity * |q|
+                sk = (a.space == SP_ANGULAR ? cosf(dk) : 1.0f - dk) * qn;
+                e = 3.0518e-5f * qn;
+            }
+            const float t = a.thr[q];
+            e += 1e-6f * (fabsf(sk) + fabsf(t));  // rounding of sk itself
+            if (!(sk - t >= e)) atomicOr(&a.tile_fail[q / a.fail_queries], 1);
+        }
+    }
     for (int i = tid; i < a.k; i += blockDim.x) {
         int32_t id = -1;
         float d = INFINITY;
@@ -1584,6 +1645,18 @@ __global__ __launch_bounds__(256) void bf_rerank_f32_list_kernel(RerankListF32Ar
         a.out_dists[(size_t)q * a.k + i] = d;
     }
     if (tid == 0 && a.out_cnt) a.out_cnt[q] = found;
+}
+
+// largest row norm (atomicMax on the bits of a non-negative float)
+__global__ void row_maxnorm_kernel(const float* rows, int n, int ld, int dim, unsigned* out_bits) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= n) return;
+    const float* p = rows + (size_t)row * ld;
+    float s = 0.f;
+    for (int d = lane; d < dim; d += 64) s = fmaf(p[d], p[d], s);
+    s = wave_sum(s);
+    if (lane == 0) atomicMax(out_bits, __float_as_uint(sqrtf(s)));
 }
 
 // ---------------------------------------------------------------------------------------
@@ -2234,7 +2307,7 @@ hipError_t launch_bf_u8_fast(const BfU8Fast& f, int n, int nq, int k, const uint
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(bf_u8_threshold_kernel),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)f.lds_thr);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(bf_u8_threshold_kernel, dim3(f.qpad), dim3(64), f.lds_thr, s, top8, 2 * f.s_nsplit, f.r, nq, thr);
+    hipLaunchKernelGGL(bf_u8_threshold_kernel, dim3(f.qpad), dim3(256), f.lds_thr, s, top8, 2 * f.s_nsplit, f.r, nq, thr);
     e = hipMemsetAsync(tile_fail, 0, (size_t)f.nqt * 4, s);
     if (e != hipSuccess) return e;
     // 2. scan with fixed thresholds
@@ -2301,7 +2374,8 @@ BfF32Fast bf_f32_fast_plan(int n, int dim, int nq, int k, int space, bool cosine
     const int tq = 256 * f.qg;
     f.qpad = (nq + tq - 1) / tq * tq;
     f.nqt = f.qpad / tq;
-    f.stride = 8;
+    f.stride = 16;  // (measured at C2: 8 -> 0.931, 16 -> 0.915, 32 -> 0.934 ms/step: a smaller sample is cheaper but lets more rows pass)
+    if (const char* e = getenv("NMSLIB_GPU_SAMPLE_STRIDE")) f.stride = atoi(e) > 0 ? atoi(e) : 16;
     // float spaces keep a slack of k' - k rows for the re-rank (the selection score is not the reference formula):
     // aim the threshold at k' = k + max(4, k/8)
     const int kp = k + (k / 8 > 4 ? k / 8 : 4);
@@ -2336,6 +2410,13 @@ BfF32Fast bf_f32_fast_plan(int n, int dim, int nq, int k, int space, bool cosine
     return f;
 }
 
+hipError_t launch_row_maxnorm(const float* rows, int n, int ld, int dim, float* out, hipStream_t s) {
+    hipError_t e = hipMemsetAsync(out, 0, 4, s);
+    if (e != hipSuccess || n == 0) return e;
+    hipLaunchKernelGGL(row_maxnorm_kernel, dim3((n + 3) / 4), dim3(256), 0, s, rows, n, ld, dim, reinterpret_cast<unsigned*>(out));
+    return hipGetLastError();
+}
+
 hipError_t launch_split_bf16(const float* src, int rows, int rows_pad, int ld, int dim, void* hi, void* lo,
                              const float* aux, float aux_pad, float* auxp, hipStream_t s) {
     const size_t total = (size_t)rows_pad * 128;
@@ -2364,7 +2445,7 @@ static hipError_t launch_scan_f32_mode(const BfScanF32Args& a, bool sample, int 
 
 hipError_t launch_bf_f32_fast(const BfF32Fast& f, int space, int n, int dim, int ldb, int nq, int k, const float* base_orig,
                               const float* sel_rows, const float* aux, const void* base_hi, const void* base_lo,
-                              const float* auxp, const float* queries_orig, const float* queries_sel, void* q_hi,
+                              const float* auxp, float bmax, const float* queries_orig, const float* queries_sel, void* q_hi,
                               void* q_lo, float* top8, unsigned long long* cand_fb, int* cnt_fb, float* thr,
                               uint32_t* list, int* list_cnt, int* tile_fail, const int32_t* ext_ids, int32_t* out_ids,
                               float* out_dists, int32_t* out_cnt, hipEvent_t scan_begin, hipEvent_t scan_end,
@@ -2396,7 +2477,7 @@ hipError_t launch_bf_f32_fast(const BfF32Fast& f, int space, int n, int dim, int
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(bf_f32_threshold_kernel),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)f.lds_thr);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(bf_f32_threshold_kernel, dim3(f.qpad), dim3(64), f.lds_thr, s, top8, 2 * f.s_nsplit, f.r, nq, thr);
+    hipLaunchKernelGGL(bf_f32_threshold_kernel, dim3(f.qpad), dim3(256), f.lds_thr, s, top8, 2 * f.s_nsplit, f.r, nq, thr);
     e = hipMemsetAsync(tile_fail, 0, (size_t)f.nqt * 4, s);
     if (e != hipSuccess) return e;
     // 2. scan with fixed thresholds
@@ -2431,6 +2512,9 @@ hipError_t launch_bf_f32_fast(const BfF32Fast& f, int space, int n, int dim, int
     r.space = space;
     r.dim = dim;
     r.ldb = ldb;
+    r.queries_sel = queries_sel;
+    r.thr = thr;
+    r.bmax = bmax;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(bf_rerank_f32_list_kernel),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)f.lds_rerank);
     if (e != hipSuccess) return e;

@@ -134,11 +134,13 @@ inline size_t bf_f32_listcnt_elems(const BfF32Fast& f) { return (size_t)f.qpad *
 inline size_t bf_f32_top8_elems(const BfF32Fast& f) { return (size_t)f.qpad * f.s_nsplit * 2 * 8; }
 inline int bf_f32_rows_padded(int n) { return (n + BF_BN - 1) / BF_BN * BF_BN + BF_BN; }
 // rows (or queries) -> bf16 hi / lo tiles [rows_pad][128]; auxp [rows_pad] = aux, aux_pad behind `rows` (optional)
+// largest row norm -> *out (device float)
+hipError_t launch_row_maxnorm(const float* rows, int n, int ld, int dim, float* out, hipStream_t s);
 hipError_t launch_split_bf16(const float* src, int rows, int rows_pad, int ld, int dim, void* hi, void* lo,
                              const float* aux, float aux_pad, float* auxp, hipStream_t s);
 hipError_t launch_bf_f32_fast(const BfF32Fast& f, int space, int n, int dim, int ldb, int nq, int k, const float* base_orig,
                               const float* sel_rows, const float* aux, const void* base_hi, const void* base_lo,
-                              const float* auxp, const float* queries_orig, const float* queries_sel, void* q_hi,
+                              const float* auxp, float bmax, const float* queries_orig, const float* queries_sel, void* q_hi,
                               void* q_lo, float* top8, unsigned long long* cand_fb, int* cnt_fb, float* thr,
                               uint32_t* list, int* list_cnt, int* tile_fail, const int32_t* ext_ids, int32_t* out_ids,
                               float* out_dists, int32_t* out_cnt, hipEvent_t scan_begin, hipEvent_t scan_end,
