@@ -1036,25 +1036,20 @@ __global__ __launch_bounds__(256, 2) void bf_scan_u8_kernel(BfScanArgs a) {
         m1 = max(m1, c1[15]);
         const int tg = thr[g];
         if constexpr (SAMPLE) {
+            // only the best value of each 32-row block enters the lane's top-8: any threshold is admissible (the
+            // re-rank verifies the outcome), a second value of the same block among a lane's eight best is rare, and
+            // examining all 32 values whenever ANY of the 64 lanes has a hit would cost 16x the instructions
             if (__any(max(m0, m1) > tg)) {
                 auto ins = [&](int v) __attribute__((always_inline)) {
-                    if (v > t8[g][7]) {
 #pragma unroll
-                        for (int i = 0; i < 8; ++i) {
-                            const int hi = max(t8[g][i], v);
-                            v = min(t8[g][i], v);
-                            t8[g][i] = hi;
-                        }
+                    for (int i = 0; i < 8; ++i) {
+                        const int hi = max(t8[g][i], v);
+                        v = min(t8[g][i], v);
+                        t8[g][i] = hi;
                     }
                 };
-                if (__any(m0 > tg)) {
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) ins(c0[i]);
-                }
-                if (__any(m1 > tg)) {
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) ins(c1[i]);
-                }
+                ins(m0);
+                ins(m1);
                 thr[g] = t8[g][7];
             }
         } else if (__any(max(m0, m1) >= tg)) {
@@ -1180,16 +1175,37 @@ __global__ __launch_bounds__(256) void bf_rerank_u8_list_kernel(RerankListArgs a
     __shared__ int s_over;
     const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nl = 2 * a.nsplit;
-    if (tid == 0) {
-        int o = 0, over = 0;
-        for (int s = 0; s < nl; ++s) {
-            offs[s] = o;
-            const int c = a.list_cnt[(size_t)q * nl + s];
-            over |= c > a.caph;
-            o += c < a.caph ? c : a.caph;
+    // exclusive prefix sum of the (clipped) list lengths: wave 0, each lane a run of consecutive lists
+    if (tid == 0) s_over = 0;
+    __syncthreads();
+    if (tid < 64) {
+        const int per = (nl + 63) / 64;
+        int sum = 0, over = 0;
+        for (int i = 0; i < per; ++i) {
+            const int s = tid * per + i;
+            if (s < nl) {
+                const int c = a.list_cnt[(size_t)q * nl + s];
+                over |= c > a.caph;
+                sum += c < a.caph ? c : a.caph;
+            }
         }
-        offs[nl] = o;
-        s_over = over;
+        int incl = sum;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int v = __shfl_up(incl, o, 64);
+            if (tid >= o) incl += v;
+        }
+        int run = incl - sum;
+        for (int i = 0; i < per; ++i) {
+            const int s = tid * per + i;
+            if (s < nl) {
+                offs[s] = run;
+                const int c = a.list_cnt[(size_t)q * nl + s];
+                run += c < a.caph ? c : a.caph;
+            }
+        }
+        if (tid == 63) offs[nl] = incl;
+        if (__any(over != 0) && tid == 0) s_over = 1;
     }
     __syncthreads();
     const int total = offs[nl];
@@ -1368,18 +1384,15 @@ __global__ __launch_bounds__(512, 2) void bf_scan_f32_kernel(BfScanF32Args a) {
     };
     auto finish_check = [&](float m, const f32x16& c, int g, const float* ax, int row0) __attribute__((always_inline)) {
         if constexpr (SAMPLE) {
+            // only the block's best value enters the lane's top-8 (see bf_scan_u8_kernel); pad rows of the dot / cosine
+            // modes score 0: the tile that holds them keeps its real maximum out of the estimate only if that is negative
             if (__any(m > thr[g])) {
+                float v = (row0 + 32 <= a.n || MODE == SC_L2) ? m : -INFINITY;
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    float v = score_of(c, i, ax);
-                    if (v > t8[g][7] && row0 + acc_row(i, h) < a.n) {
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) {
-                            const float hi = fmaxf(t8[g][j], v);
-                            v = fminf(t8[g][j], v);
-                            t8[g][j] = hi;
-                        }
-                    }
+                for (int j = 0; j < 8; ++j) {
+                    const float hi = fmaxf(t8[g][j], v);
+                    v = fminf(t8[g][j], v);
+                    t8[g][j] = hi;
                 }
                 thr[g] = t8[g][7];
             }
@@ -1551,16 +1564,37 @@ __global__ __launch_bounds__(256) void bf_rerank_f32_list_kernel(RerankListF32Ar
     __shared__ int s_over;
     const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nl = 2 * a.nsplit;
-    if (tid == 0) {
-        int o = 0, over = 0;
-        for (int s = 0; s < nl; ++s) {
-            offs[s] = o;
-            const int c = a.list_cnt[(size_t)q * nl + s];
-            over |= c > a.caph;
-            o += c < a.caph ? c : a.caph;
+    // exclusive prefix sum of the (clipped) list lengths: wave 0, each lane a run of consecutive lists
+    if (tid == 0) s_over = 0;
+    __syncthreads();
+    if (tid < 64) {
+        const int per = (nl + 63) / 64;
+        int sum = 0, over = 0;
+        for (int i = 0; i < per; ++i) {
+            const int s = tid * per + i;
+            if (s < nl) {
+                const int c = a.list_cnt[(size_t)q * nl + s];
+                over |= c > a.caph;
+                sum += c < a.caph ? c : a.caph;
+            }
         }
-        offs[nl] = o;
-        s_over = over;
+        int incl = sum;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int v = __shfl_up(incl, o, 64);
+            if (tid >= o) incl += v;
+        }
+        int run = incl - sum;
+        for (int i = 0; i < per; ++i) {
+            const int s = tid * per + i;
+            if (s < nl) {
+                offs[s] = run;
+                const int c = a.list_cnt[(size_t)q * nl + s];
+                run += c < a.caph ? c : a.caph;
+            }
+        }
+        if (tid == 63) offs[nl] = incl;
+        if (__any(over != 0) && tid == 0) s_over = 1;
     }
     __syncthreads();
     const int total = offs[nl];
