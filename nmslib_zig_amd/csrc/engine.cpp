@@ -766,7 +766,7 @@ void Engine::finalize() {
             d_auxp_.release();
             const bool fast_space = space_ == SP_L2 || space_ == SP_NEGDOT ||
                                     ((space_ == SP_COSINE || space_ == SP_ANGULAR) && !centred_);
-            if (fast_space && dim_ <= 128 && n >= 131072) {
+            if (fast_space && dim_ <= 128 && n >= 65536) {
                 const size_t n_pad = (size_t)bf_f32_rows_padded((int)n);
                 d_bf_hi_.ensure(n_pad * 128 * 2);
                 d_bf_lo_.ensure(n_pad * 128 * 2);

@@ -2258,7 +2258,7 @@ hipError_t launch_bf_rerank_ex(const BfPlan& p, int space, int dim, int k, const
 // ---- uint8 fast path (see bf_scan_u8_kernel) ----------------------------------------------------------------
 BfU8Fast bf_u8_fast_plan(int n, int nq, int k) {
     BfU8Fast f{};
-    f.use = (n >= 131072 && nq >= 512 && k <= 256);
+    f.use = (n >= 65536 && nq >= 512 && k <= 256);
     if (const char* e = getenv("NMSLIB_GPU_U8_FAST")) f.use = f.use && atoi(e) != 0;
     if (!f.use) return f;
     f.qg = nq >= 2048 ? 4 : 2;
@@ -2396,7 +2396,7 @@ hipError_t launch_bf_u8_fast(const BfU8Fast& f, int n, int nq, int k, const uint
 BfF32Fast bf_f32_fast_plan(int n, int dim, int nq, int k, int space, bool cosine_centred) {
     BfF32Fast f{};
     const bool space_ok = space == SP_L2 || space == SP_NEGDOT || ((space == SP_COSINE || space == SP_ANGULAR) && !cosine_centred);
-    f.use = space_ok && dim <= 128 && n >= 131072 && nq >= 256 && k <= 128;
+    f.use = space_ok && dim <= 128 && n >= 65536 && nq >= 256 && k <= 128;
     if (const char* e = getenv("NMSLIB_GPU_F32_FAST")) f.use = f.use && atoi(e) != 0;
     if (!f.use) return f;
     f.mode = space == SP_L2 ? 0 : (space == SP_NEGDOT ? 1 : 2);

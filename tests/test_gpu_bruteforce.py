@@ -321,10 +321,10 @@ def test_uncentred_data(space, offset):
 
 @pytest.mark.parametrize("kind", ["sift_like", "heavy_ties"])
 def test_u8_fast_path_large_batch_bit_exact(kind):
-    """Batches of >= 512 queries on >= 128k rows take the sample-threshold + streaming-scan path (bf_scan_u8_kernel);
+    """Batches of >= 512 queries on >= 64k rows take the sample-threshold + streaming-scan path (bf_scan_u8_kernel);
     it must stay bit-exact.  heavy_ties: a 3-symbol alphabet makes thousands of rows share the threshold score, the
     lists overflow and the flagged query tiles are redone by the adaptive kernel -- still exact, incl. tie order."""
-    n, nq, k = 140000, 640, 100
+    n, nq, k = 70000, 640, 100
     if kind == "sift_like":
         U, UQ = refio.s_sift_like(n, 91), refio.s_sift_like(nq, 92)
     else:
@@ -352,11 +352,11 @@ def test_u8_fast_path_large_batch_bit_exact(kind):
 @pytest.mark.parametrize("space,D,offset", [("l2", 128, 0.0), ("l2", 100, 0.0), ("l2", 128, 1000.0), ("negdotprod", 128, 0.0),
                                             ("cosinesimil", 128, 0.0), ("angulardist", 64, 0.0)])
 def test_f32_fast_path_large_batch(space, D, offset):
-    """Batches of >= 256 queries on >= 128k rows at D <= 128 take the split-bf16 selection with sample-fixed thresholds
+    """Batches of >= 256 queries on >= 64k rows at D <= 128 take the split-bf16 selection with sample-fixed thresholds
     (bf_scan_f32_kernel); the re-rank is the reference formula in f32 on the original rows, the verification + adaptive
     fallback make the result independent of the bf16 approximation.  Planted duplicates overflow the lists of the queries
     next to them (exercises the fallback)."""
-    n, nq, k = 140000, 384, 10
+    n, nq, k = 70000, 384, 10
     X = (refio.s_lowrank(n, D, 71) + np.float32(offset)).astype(np.float32)
     Q = (refio.s_lowrank(nq, D, 72) + np.float32(offset)).astype(np.float32)
     X[2000:2400] = X[11]                                           # 400 identical rows
