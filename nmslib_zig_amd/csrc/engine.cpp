@@ -953,10 +953,25 @@ void Engine::knn_device(const void* d_queries, size_t nq, size_t elem_count, siz
 void Engine::knn_brute(const void* d_queries, size_t nq, size_t k, int32_t* d_ids, float* d_dists, int32_t* d_cnt,
                        hipStream_t stream) {
     have_counters_ = false;
-    if (k > (size_t)BF_MAX_K)
-        throw EngineError(Err::QueryTooLarge, "k larger than " + std::to_string(BF_MAX_K) +
-                                                  " is not supported by the brute-force GPU kernels");
     const int dim_eff = d_n_ ? (int)dim_ : 1;
+    if (k > (size_t)BF_MAX_K) {
+        // beyond the selection kernels' capacity: per query one pass with the reference formula + one stable radix sort
+        const int ld = is_u8() ? 128 : ldb_;
+        const int elem = is_u8() ? 1 : 4;
+        const size_t n = d_n_;
+        ws_qpad_.ensure(std::max<size_t>(nq, 1) * ld * elem);
+        hip_check(launch_pad_rows(d_queries, (int)nq, dim_eff, ws_qpad_.ptr(), (int)nq, ld, elem, stream), "pad queries");
+        ws_rdist_.ensure(std::max<size_t>(n, 1) * 4);
+        ws_bigk_.ensure(std::max<size_t>(n, 1) * 16);
+        const size_t tb = bf_bigk_temp_bytes((int)n);
+        ws_bigk_tmp_.ensure(tb);
+        hip_check(launch_bf_bigk(space_, d_rows_.ptr(), ld, (int)n, ws_qpad_.ptr(), (size_t)ld * elem, (int)nq, dim_eff, (int)k,
+                                 d_ids_.as<int32_t>(), ws_rdist_.as<float>(), ws_bigk_.as<uint32_t>(), ws_bigk_tmp_.ptr(), tb,
+                                 d_ids, d_dists, d_cnt, stream),
+                  "bf_bigk");
+        last_path = 5;
+        return;
+    }
     if (is_u8()) {
         // large batches: thresholds fixed by a sample pass, then one streaming scan (bf_kernels.hip, bf_scan_u8_kernel)
         const BfU8Fast f = bf_u8_fast_plan((int)d_n_, (int)nq, (int)k);

@@ -189,7 +189,7 @@ class Engine {
     size_t view_lo_ = 0, view_n_ = 0;
     int forced_device_ = -1;
     int gpu_shards_ = -1;  // index parameter: -1 unset, 0 = all visible devices, N = that many
-    DevBuf ws_sh_ids_, ws_sh_d_;
+    DevBuf ws_sh_ids_, ws_sh_d_, ws_bigk_, ws_bigk_tmp_;
     void* pinned(size_t bytes);
     void* pinned_ = nullptr;
     size_t pinned_bytes_ = 0;

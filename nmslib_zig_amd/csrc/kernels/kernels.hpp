@@ -266,6 +266,13 @@ hipError_t launch_range_search(int space, const void* rows, int ld, int n, const
                                float radius, const int32_t* ext_ids, float* dist_ws, int* count_ws, int capacity,
                                int32_t* out_ids, float* out_dists, hipStream_t s);
 
+// Exact scan for k > BF_MAX_K: per query one pass with the reference formula + one stable device radix sort of
+// (distance, position).  dist_ws [n] floats, key_ws [4][n] u32, temp from bf_bigk_temp_bytes(n).
+size_t bf_bigk_temp_bytes(int n);
+hipError_t launch_bf_bigk(int space, const void* rows, int ld, int n, const void* queries_padded, size_t query_stride_bytes,
+                          int nq, int dim, int k, const int32_t* ext_ids, float* dist_ws, uint32_t* key_ws, void* temp,
+                          size_t temp_bytes, int32_t* out_ids, float* out_dists, int32_t* out_cnt, hipStream_t s);
+
 // ---- shard merge ---------------------------------------------------------------------------
 // shard s's lists start at dists_in + s*shard_stride / ids_in + s*shard_stride (elements)
 hipError_t launch_merge_topk(const float* dists_in, const int32_t* ids_in, size_t shard_stride, int nshards, int nq,

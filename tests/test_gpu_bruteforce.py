@@ -112,15 +112,27 @@ def test_edge_cases_small_and_empty():
     assert len(idx.alloc.live) == 0
 
 
-def test_large_k_and_k_limit():
+def test_large_k_no_limit():
+    """k up to 512 runs on the selection kernels; beyond that (the reference has no limit, knnquery.cc:66-75) every query
+    takes one pass with the reference formula + one stable radix sort of (distance, position): still exact."""
     X, Q = refio.s_gauss(2000, 32, 3), refio.s_gauss(9, 32, 4)
+    X[700:720] = X[5]                                                          # ties: positions decide
     idx = make_index("l2", "seq_search", X)
-    ids, ds, cnt = idx.knnQueryBatch(Q, 512)
-    opos, odist, _ = orc.seq_search("l2", X, Q, 512)
-    assert (ids == opos).mean() >= 0.999 and close_rel(ds, odist)
-    with pytest.raises(nz.NmslibError) as e:
-        idx.knnQueryBatch(Q, 513)
-    assert e.value.code == 6                                                   # QUERY_TOO_LARGE
+    for k in (512, 513, 1500):
+        ids, ds, cnt = idx.knnQueryBatch(Q, k)
+        opos, odist, _ = orc.seq_search("l2", X, Q, k)
+        assert (cnt == k).all()
+        assert (ids == opos).mean() >= 0.999 and close_rel(ds, odist)
+    ids, ds, cnt = idx.knnQueryBatch(Q, 2500)                                  # more than there are rows
+    assert (cnt == 2000).all() and (ids[:, 2000:] == -1).all() and np.isinf(ds[:, 2000:]).all()
+    assert all(sorted(r[:2000].tolist()) == list(range(2000)) for r in ids)
+    idx.close()
+    U = refio.s_sift_like(3000, 5)
+    idx = make_index("l2sqr_sift", "seq_search", U)
+    ids, ds, cnt = idx.knnQueryBatch(U[:4], 800)
+    opos, odist, _ = orc.seq_search("l2sqr_sift", U, U[:4], 800)
+    np.testing.assert_array_equal(ds, odist)
+    np.testing.assert_array_equal(ids, opos)
     idx.close()
 
 
