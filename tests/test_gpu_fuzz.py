@@ -82,3 +82,36 @@ def test_hnsw_random_shapes_same_graph(seed):
     if dim > 3:
         assert (ids[valid] == opos[valid]).mean() >= 0.99, (space, n, dim, M, ef, k)
     idx.close()
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_fast_paths_random_shapes(seed):
+    """The large-batch fast paths (sample-fixed thresholds + streaming scan; float rows through the split-bf16 MFMA, bytes
+    through the int8 MFMA) on random shapes around their switch-over points: row counts just above 64k that are not
+    multiples of the tile, batches that are not multiples of the query tile, k from 1 to 128, D from 8 to 128, data with
+    and without a common offset; gaussian data (no structure: the hardest case for a fixed threshold)."""
+    rng = np.random.default_rng(3000 + seed)
+    space = ("l2", "l2sqr_sift", "negdotprod", "cosinesimil", "l2", "angulardist")[seed % 6]
+    n = int(rng.choice([65536, 65537, 70001, 100003]))
+    dim = 128 if space == "l2sqr_sift" else int(rng.choice([8, 24, 64, 100, 128]))
+    nq = int(rng.choice([512, 513, 700, 1025]))
+    k = int(rng.choice([1, 10, 37, 100, 128]))
+    if space == "l2sqr_sift":
+        X, Q = refio.s_sift_like(n, 50 + seed), refio.s_sift_like(nq, 60 + seed)
+    else:
+        off = np.float32(50.0 if (space == "l2" and seed % 2) else 0.0)
+        X, Q = refio.s_gauss(n, dim, 50 + seed) + off, refio.s_gauss(nq, dim, 60 + seed) + off
+    idx = make_index(space, "seq_search", X)
+    ids, ds, cnt = idx.knnQueryBatch(Q, k)
+    assert (cnt == k).all()
+    sel = np.r_[0:6, nq - 6:nq]
+    opos, odist, _ = orc.seq_search(space, X, Q[sel], k + 22)
+    if space == "l2sqr_sift":
+        np.testing.assert_array_equal(ds[sel], odist[:, :k])
+        np.testing.assert_array_equal(ids[sel], opos[:, :k])
+    else:
+        rec = refio.recall_nmslib(ids[sel], opos, odist, k)
+        assert rec >= 0.999, (space, n, dim, nq, k, rec)
+        rtol, atol = (1e-4, 1e-5) if space == "angulardist" else (1e-5, 1e-6)
+        assert close_rel(ds[sel], odist[:, :k], rtol=rtol, atol=atol * max(1.0, float(np.abs(X).max()))), (space, n, dim, nq, k)
+    idx.close()
