@@ -1020,8 +1020,11 @@ __global__ __launch_bounds__(256, 2) void bf_scan_u8_kernel(BfScanArgs a) {
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): retire the query loads before any DMA is counted
 
-    for (int t = 0; t < kRing - 1 && t < nstages; ++t) issue_tile(t);
-    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    // Tiles are consumed in PAIRS: one counted wait + workgroup barrier per two tiles (128 rows).  Ring of six slots =
+    // the pair being read, the pair in flight behind it, the pair just requested.
+    for (int t = 0; t < 4 && t < nstages; ++t) issue_tile(t);
+    if (nstages > 2) asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");   // tiles 0, 1 landed; 2, 3 in flight
+    else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
 
     const int sw = (l31 >> 1) & 7;
     // rows of one finished 32 x 64 block pair that reach the threshold: position appended to the lane's list
@@ -1074,7 +1077,7 @@ __global__ __launch_bounds__(256, 2) void bf_scan_u8_kernel(BfScanArgs a) {
         }
     };
 
-    for (int t = 0; t < nstages; ++t) {
+    auto process_tile = [&](int t) __attribute__((always_inline)) {
         const char* tp = ring + (t % kRing) * kTileBytes + l31 * 128;
         const int* ax = auxr + (t % kAuxRing) * BF_BN + 4 * h;
         const int row0 = r_begin + t * stage_rows;
@@ -1097,8 +1100,6 @@ __global__ __launch_bounds__(256, 2) void bf_scan_u8_kernel(BfScanArgs a) {
                 init1[4 * j + i] = v1[i];
             }
         }
-        // the slot of tile t+5 held tile t-1: every wave passed the barrier that ended stage t-1 after its reads
-        if (t + kRing - 1 < nstages) issue_tile(t + kRing - 1);
         i32x16 p0, p1;  // scores of the previous query group, examined under the MFMAs of the current one
 #pragma unroll
         for (int g = 0; g < QG; ++g) {
@@ -1113,8 +1114,17 @@ __global__ __launch_bounds__(256, 2) void bf_scan_u8_kernel(BfScanArgs a) {
             p1 = c1;
         }
         examine(p0, p1, QG - 1, row0);
-        // tile t+1 must have landed; tiles t+2 .. t+5 (3 DMA instructions each) may stay in flight
-        if (t + kRing - 1 < nstages) asm volatile("s_waitcnt vmcnt(12)\n\ts_barrier" ::: "memory");
+    };
+    for (int t = 0; t < nstages; t += 2) {
+        // the slots of tiles t+4, t+5 held tiles t-2, t-1: every wave passed the last barrier after reading them
+        const int nnew = (t + 4 < nstages ? 1 : 0) + (t + 5 < nstages ? 1 : 0);
+        if (t + 4 < nstages) issue_tile(t + 4);
+        if (t + 5 < nstages) issue_tile(t + 5);
+        process_tile(t);
+        if (t + 1 < nstages) process_tile(t + 1);
+        // tiles t+2, t+3 must have landed; the tiles requested above (3 DMA instructions each) may stay in flight
+        if (nnew == 2) asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
+        else if (nnew == 1) asm volatile("s_waitcnt vmcnt(3)\n\ts_barrier" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
     }
 #pragma unroll
