@@ -358,9 +358,9 @@ nmslib_error_t nmslib_knn_query_batch(nmslib_index_handle_t index, const void* q
     bool too_small = false;
     nmslib_error_t rc = guarded(NMSLIB_ERROR_QUERY_EXECUTION_FAILED, "KNN query failed", [&] {
         std::lock_guard<std::mutex> lk(e->mu);
-        std::vector<int32_t> ids, cnt;
-        std::vector<float> dists;
-        e->knn_host(queries, query_count, query_size_or_elem_count, k, ids, dists, cnt);
+        const int32_t *ids = nullptr, *cnt = nullptr;
+        const float* dists = nullptr;
+        e->knn_host(queries, query_count, query_size_or_elem_count, k, &ids, &dists, &cnt);
         for (size_t i = 0; i < query_count; ++i) {
             fill_result(&results[i], &ids[i * k], &dists[i * k], (size_t)cnt[i]);
             too_small |= ((size_t)cnt[i] > results[i].capacity);

@@ -1212,8 +1212,8 @@ void* Engine::pinned(size_t bytes) {
     return pinned_;
 }
 
-void Engine::knn_host(const void* queries, size_t nq, size_t elem_count, size_t k, std::vector<int32_t>& ids,
-                      std::vector<float>& dists, std::vector<int32_t>& cnt) {
+void Engine::knn_host(const void* queries, size_t nq, size_t elem_count, size_t k, const int32_t** ids, const float** dists,
+                      const int32_t** cnt) {
     if (!created_) throw EngineError(Err::IndexBuildFailed, "Index not built");
     if (dirty_) finalize();
     check_device();
@@ -1231,12 +1231,9 @@ void Engine::knn_host(const void* queries, size_t nq, size_t elem_count, size_t 
     knn_device(ws_q_.ptr(), nq, elem_count, k, d_ids, d_dists, d_cnt, stream_);
     hip_check(hipMemcpyAsync(hp, d_ids, 2 * rbytes + nq * 4, hipMemcpyDeviceToHost, stream_), "results D2H");
     hip_check(hipStreamSynchronize(stream_), "knn");
-    ids.resize(nq * k);
-    dists.resize(nq * k);
-    cnt.resize(nq);
-    std::memcpy(ids.data(), hp, rbytes);
-    std::memcpy(dists.data(), hp + rbytes, rbytes);
-    std::memcpy(cnt.data(), hp + 2 * rbytes, nq * 4);
+    *ids = reinterpret_cast<const int32_t*>(hp);
+    *dists = reinterpret_cast<const float*>(hp + rbytes);
+    *cnt = reinterpret_cast<const int32_t*>(hp + 2 * rbytes);
 }
 
 size_t Engine::range_host(const void* query, size_t elem_count, double radius, size_t capacity, int32_t* ids,

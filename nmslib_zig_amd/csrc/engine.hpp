@@ -143,8 +143,9 @@ class Engine {
     // k-NN: device-resident batch (the hot entry) and host convenience wrapper
     void knn_device(const void* d_queries, size_t nq, size_t elem_count, size_t k, int32_t* d_ids,
                     float* d_dists, int32_t* d_cnt, hipStream_t stream);
-    void knn_host(const void* queries, size_t nq, size_t elem_count, size_t k, std::vector<int32_t>& ids,
-                  std::vector<float>& dists, std::vector<int32_t>& cnt);
+    // host buffers in, results in this engine's pinned staging block (valid until the next call; the caller holds `mu`)
+    void knn_host(const void* queries, size_t nq, size_t elem_count, size_t k, const int32_t** ids, const float** dists,
+                  const int32_t** cnt);
     float pair_distance(size_t p1, size_t p2);
     // RangeQuery on the brute-force index: matches in insertion order, the first `capacity`; returns how many were written
     size_t range_host(const void* query, size_t elem_count, double radius, size_t capacity, int32_t* ids, float* dists);

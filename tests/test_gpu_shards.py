@@ -77,3 +77,26 @@ def test_sharded_hnsw_recall_and_save_is_refused(tmp_path):
                 idx.save(str(tmp_path / "sharded.idx"), save_data=False)
         idx.close()
     assert rec[2] >= rec[1] - 0.002, rec        # each shard returns its local top-k: never worse than one graph
+
+
+@pytest.mark.parametrize("space", ["l2", "l2sqr_sift"])
+def test_sharded_fast_paths_equal_unsharded(space):
+    """Shards big enough (>= 64k rows each, >= 512 queries) for the large-batch fast paths: per-shard sample thresholds,
+    scans and list re-ranks, then the merge -- still the unsharded result bit for bit."""
+    n, nq = 140003, 600
+    if space == "l2sqr_sift":
+        X, Q, k = refio.s_sift_like(n, 21), refio.s_sift_like(nq, 22), 100
+    else:
+        X, Q, k = refio.s_lowrank(n, 128, 21), refio.s_lowrank(nq, 128, 22), 10
+        X[69990:70020] = X[3]                       # duplicates across the shard border
+        Q[0] = X[3]
+    one = make_index(space, "seq_search", X, gpu_shards=1)
+    two = make_index(space, "seq_search", X, gpu_shards=2)
+    a, b = one.knnQueryBatch(Q, k), two.knnQueryBatch(Q, k)
+    for x, y in zip(a, b):
+        np.testing.assert_array_equal(x, y)
+    small = one.knnQueryBatch(Q[:40], k)            # adaptive path on the same index: same rows
+    np.testing.assert_array_equal(small[0], a[0][:40])
+    np.testing.assert_array_equal(small[1], a[1][:40])
+    one.close()
+    two.close()
