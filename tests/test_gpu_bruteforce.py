@@ -390,3 +390,26 @@ def test_f32_fast_path_large_batch(space, D, offset):
     assert (ids2 == ids[:64]).mean() >= 0.999
     assert close_rel(ds2, ds[:64])
     idx.close()
+
+
+def test_fast_paths_with_batches_larger_than_one_slice():
+    """40 000 queries (slices of 32 768 + 7 232) through the fast paths: results equal small batches through the
+    adaptive path."""
+    X, Q = refio.s_gauss(66000, 32, 97), refio.s_gauss(40_000, 32, 98)
+    idx = make_index("l2", "seq_search", X)
+    ids, ds, cnt = idx.knnQueryBatch(Q, 5)
+    assert idx.stats()["last_path"] == 1
+    for lo in (0, 32760, 39950):
+        i2, d2, c2 = idx.knnQueryBatch(Q[lo:lo + 50], 5)
+        np.testing.assert_array_equal(ids[lo:lo + 50], i2)
+        np.testing.assert_array_equal(ds[lo:lo + 50], d2)
+    idx.close()
+    U, UQ = refio.s_sift_like(66000, 99), refio.s_sift_like(40_000, 100)
+    idx = make_index("l2sqr_sift", "seq_search", U)
+    ids, ds, cnt = idx.knnQueryBatch(UQ, 7)
+    assert idx.stats()["last_path"] == 3
+    for lo in (0, 32760, 39950):
+        i2, d2, c2 = idx.knnQueryBatch(UQ[lo:lo + 50], 7)
+        np.testing.assert_array_equal(ids[lo:lo + 50], i2)
+        np.testing.assert_array_equal(ds[lo:lo + 50], d2)
+    idx.close()
