@@ -925,6 +925,50 @@ __global__ __launch_bounds__(256, 2) void bf_select_u8_kernel(BfArgsU8 a) {
     if (h == 0) a.cand_cnt[(size_t)qidx * a.nsplit + split] = mycnt;
 }
 
+// ---- hit entries of the streaming scans ------------------------------------------------------------------------
+// A scan lane that finds rows at or above its threshold in a 32-row block appends ONE word per block to its list:
+// (block index inside the split) << 16 | 16-bit mask of its rows -- a dozen instructions.  The workgroup barrier at the
+// end of every stage makes all eight waves wait for the slowest, and with ~1 block in 10 holding a hit some wave is on
+// this path in most stages: decoding the mask into row positions there (a divergent loop, or 16 x if-chains) cost
+// 0.09 ms of 0.72 ms at C2.  The re-rank kernels expand the entries (scan_gather_entries).
+// mask bit (15 - i) <=> accumulator register i  (v_cmp + v_addc shift the compare results in from the right)
+__device__ __forceinline__ uint32_t hit_mask_f32(const f32x16& c, float t) {
+    uint32_t m = 0u;
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+        asm volatile("v_cmp_ge_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(m) : "v"(c[i]), "v"(t) : "vcc");
+    return m;
+}
+__device__ __forceinline__ uint32_t hit_mask_i32(const i32x16& c, int t) {
+    uint32_t m = 0u;
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+        asm volatile("v_cmp_ge_i32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(m) : "v"(c[i]), "v"(t) : "vcc");
+    return m;
+}
+// list s = (split, half) of query q: entries -> row positions at keys[offs[s] ..]; one thread per list (a handful of
+// entries each).  offs[] holds the prefix sums of the lists' POSITION counts (list_cnt), none above caph here.
+__device__ __forceinline__ void scan_gather_entries(u64* keys, const int* offs, const uint32_t* list, int q, int nl, int caph,
+                                                    int tps, int tid, int nthreads) {
+    for (int s = tid; s < nl; s += nthreads) {
+        const int len = offs[s + 1] - offs[s];
+        const uint32_t* e = list + ((size_t)q * nl + s) * caph;
+        const uint32_t row_base = (uint32_t)(s >> 1) * (uint32_t)tps * BF_BN + 4u * (s & 1);
+        int j = 0;
+        for (int i = 0; i < caph && j < len; ++i) {
+            const uint32_t ent = e[i];
+            uint32_t m = ent & 0xffffu;
+            const uint32_t r0 = row_base + (ent >> 16) * 32u;
+            while (m && j < len) {
+                const int bit = 31 - __builtin_clz(m);   // highest bit first = lowest register = lowest row
+                m &= ~(1u << bit);
+                const int reg = 15 - bit;
+                keys[offs[s] + j++] = (u64)(r0 + (reg & 3) + 8 * (reg >> 2));
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // uint8 fast path (large batches): the selection threshold of every query is FIXED before the rows are streamed.
 //   1. sample pass   - bf_select_u8_kernel over every 8th 64-row tile with k' = r: the r-th best score of the sample
@@ -946,8 +990,8 @@ struct BfScanArgs {
     const int32_t* auxh;      // [n_pad] aux >> 1 (pad rows: -2^29)
     const uint8_t* queries;   // [qpad][128]
     const int* thr;           // [qpad] pass <=> dot' + auxh >= thr
-    uint32_t* list;           // [qpad][nsplit][2][caph] row positions
-    int* list_cnt;            // [qpad][nsplit][2]
+    uint32_t* list;           // [qpad][nsplit][2][caph] hit entries: block << 16 | row mask (see hit_mask_i32)
+    int* list_cnt;            // [qpad][nsplit][2] rows listed
     int n, nqt, nsplit, tps, caph;
     int tile_stride;          // SAMPLE: every tile_stride-th tile
     int* top8;                // SAMPLE: [qpad][nsplit][2][8] best (score >> 1) values each lane saw, descending
@@ -996,7 +1040,7 @@ __global__ __launch_bounds__(256, 2) void bf_scan_u8_kernel(BfScanArgs a) {
 
     // this lane's QG queries, their thresholds, their lists (each lane owns the rows of its half h: no atomics)
     i32x4 bq[QG][4];
-    int thr[QG], cnt[QG];
+    int thr[QG], cnt[QG], ecnt[QG];   // cnt: rows listed, ecnt: list words written (one per block with a hit)
     uint32_t* lp[QG];
     int t8[SAMPLE ? QG : 1][8];
 #pragma unroll
@@ -1008,6 +1052,7 @@ __global__ __launch_bounds__(256, 2) void bf_scan_u8_kernel(BfScanArgs a) {
             bq[g][ks] = v ^ (int)0x80808080;
         }
         cnt[g] = 0;
+        ecnt[g] = 0;
         if constexpr (SAMPLE) {
             thr[g] = -(1 << 28);  // above the pad rows' -2^29: they never enter the lists
             lp[g] = nullptr;
@@ -1056,24 +1101,18 @@ __global__ __launch_bounds__(256, 2) void bf_scan_u8_kernel(BfScanArgs a) {
                 thr[g] = t8[g][7];
             }
         } else if (__any(max(m0, m1) >= tg)) {
-            if (__any(m0 >= tg)) {
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    if (c0[i] >= tg) {
-                        if (cnt[g] < a.caph) lp[g][cnt[g]] = (uint32_t)(row0 + acc_row(i, h));
-                        cnt[g]++;
-                    }
-                }
+            // one entry per 32-row block with a hit (see hit_mask_i32): the re-rank expands them
+            const uint32_t blk = (uint32_t)(row0 - r_begin) >> 5;
+            const uint32_t k0 = hit_mask_i32(c0, tg), k1 = hit_mask_i32(c1, tg);
+            if (k0) {
+                if (ecnt[g] < a.caph) lp[g][ecnt[g]] = (blk << 16) | k0;
+                ecnt[g]++;
             }
-            if (__any(m1 >= tg)) {
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    if (c1[i] >= tg) {
-                        if (cnt[g] < a.caph) lp[g][cnt[g]] = (uint32_t)(row0 + 32 + acc_row(i, h));
-                        cnt[g]++;
-                    }
-                }
+            if (k1) {
+                if (ecnt[g] < a.caph) lp[g][ecnt[g]] = ((blk + 1) << 16) | k1;
+                ecnt[g]++;
             }
+            cnt[g] += __builtin_popcount(k0) + __builtin_popcount(k1);
         }
     };
 
@@ -1176,6 +1215,7 @@ struct RerankListArgs {
     int32_t* out_cnt;
     int* tile_fail;           // [ceil(nq / fail_queries)]
     int n, k, nsplit, caph, p2max, fail_queries;
+    int tps;                  // tiles per split of the scan (entries hold block indices inside their split)
 };
 
 __global__ __launch_bounds__(256) void bf_rerank_u8_list_kernel(RerankListArgs a) {
@@ -1226,10 +1266,7 @@ __global__ __launch_bounds__(256) void bf_rerank_u8_list_kernel(RerankListArgs a
         if (tid == 0) atomicOr(&a.tile_fail[q / a.fail_queries], 1);
         return;
     }
-    for (int idx = tid; idx < nl * a.caph; idx += blockDim.x) {
-        const int s = idx / a.caph, i = idx - s * a.caph;
-        if (i < offs[s + 1] - offs[s]) keys[offs[s] + i] = (u64)a.list[((size_t)q * nl + s) * a.caph + i];
-    }
+    scan_gather_entries(keys, offs, a.list, q, nl, a.caph, a.tps, tid, blockDim.x);
     __syncthreads();
     const int P = next_pow2(total < 2 ? 2 : total);
     // sum (a-b)^2 = a.a + b.b - 2 a.b on packed bytes (exact in int32; distcomp_l2sqr_sift.cc:41-50 gives the same
@@ -1302,15 +1339,21 @@ struct BfScanF32Args {
     const __bf16* q_hi;       // [qpad][128]
     const __bf16* q_lo;
     const float* thr;         // [qpad] pass <=> score >= thr
-    uint32_t* list;           // [qpad][nsplit][2][caph]
-    int* list_cnt;            // [qpad][nsplit][2]
+    uint32_t* list;           // [qpad][nsplit][2][caph] hit entries: block << 16 | row mask (see hit_mask_f32)
+    int* list_cnt;            // [qpad][nsplit][2] rows listed
     int n, nqt, nsplit, tps, caph;
     int tile_stride;          // SAMPLE
     float* top8;              // SAMPLE: [qpad][nsplit][2][8]
 };
 
+// Workgroup = 4 waves, ONE per SIMD, each with the SIMD's whole 512-entry register file; a wave serves QG groups of 32
+// queries (QG = 4: 512 queries per workgroup, 256 registers of query fragments; QG = 2: 256 queries), so that every
+// fragment read from LDS feeds 3 * QG MFMAs.  (The first shape of this kernel -- 8 waves x 32 queries, two waves per
+// SIMD -- read 20 ds_read_b128 per wave and block: the LDS port was busy 1280 of the 1536 clocks the block's MFMAs
+// take, and two query groups per wave spilled at 256 registers.)
 template <int MODE, bool SAMPLE, int QG>
-__global__ __launch_bounds__(512, 2) void bf_scan_f32_kernel(BfScanF32Args a) {
+__global__ __launch_bounds__(256) void bf_scan_f32_kernel(BfScanF32Args a) {
+    constexpr int NW = 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = lane >> 5, l31 = lane & 31;
@@ -1331,13 +1374,15 @@ __global__ __launch_bounds__(512, 2) void bf_scan_f32_kernel(BfScanF32Args a) {
     const int r_begin = split * a.tps * tstr * BF_BN;
     const int stage_rows = tstr * BF_BN;
 
-    // one stage = 32 DMA pieces of 1 KiB (4 rows x 256 B): wave w issues pieces 4w .. 4w+3 (0..15 hi tile, 16..31 lo tile)
+    // one stage = 32 DMA pieces of 1 KiB (4 rows x 256 B; 0..15 hi tile, 16..31 lo tile): wave w issues pieces
+    // kPieces * w .. + kPieces - 1, and its share of the stage's 64 aux values
+    constexpr int kPieces = 32 / NW, kAuxLanes = BF_BN / NW;
     auto issue_tile = [&](int stage) __attribute__((always_inline)) {
         const int slot = stage % kRing;
         const int row0 = r_begin + stage * stage_rows;
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-            const int j = 4 * wave + jj;
+        for (int jj = 0; jj < kPieces; ++jj) {
+            const int j = kPieces * wave + jj;
             const int half = j >> 4, pj = j & 15;     // piece pj of its tile = rows 4*pj .. 4*pj+3
             const int row = 4 * pj + (lane >> 4);
             const int c = (lane & 15) ^ (row & 15);
@@ -1345,26 +1390,29 @@ __global__ __launch_bounds__(512, 2) void bf_scan_f32_kernel(BfScanF32Args a) {
             __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(ring + slot * kStageBytes + half * kHalfBytes + pj * 1024),
                                              16, 0, 0);
         }
-        if (lane < 8)
-            __builtin_amdgcn_global_load_lds((gptr_t)(a.auxp + row0 + 8 * wave + lane),
-                                             (lptr_t)(auxr + (stage % kAuxRing) * BF_BN + 8 * wave), 4, 0, 0);
+        if (lane < kAuxLanes)
+            __builtin_amdgcn_global_load_lds((gptr_t)(a.auxp + row0 + kAuxLanes * wave + lane),
+                                             (lptr_t)(auxr + (stage % kAuxRing) * BF_BN + kAuxLanes * wave), 4, 0, 0);
     };
 
     // this lane's QG queries: fragments of both halves; lane (l31, h) holds elements 16*kc + 8*h + {0..7}
     bf16x8 qh[QG][8], ql[QG][8];
     float thr[QG];
-    int cnt[QG];
+    int cnt[QG], ecnt[QG];   // cnt: rows listed, ecnt: list words written (one per block with a hit)
     uint32_t* lp[QG];
     float t8[SAMPLE ? QG : 1][8];
 #pragma unroll
     for (int g = 0; g < QG; ++g) {
-        const int qidx = (qt * 8 + wave) * (32 * QG) + g * 32 + l31;
+        const int qidx = (qt * NW + wave) * (32 * QG) + g * 32 + l31;
 #pragma unroll
         for (int kc = 0; kc < 8; ++kc) {
-            qh[g][kc] = *reinterpret_cast<const bf16x8*>(a.q_hi + (size_t)qidx * 128 + 16 * kc + 8 * h);
-            ql[g][kc] = *reinterpret_cast<const bf16x8*>(a.q_lo + (size_t)qidx * 128 + 16 * kc + 8 * h);
+            // straight into AGPRs (the MFMA reads its B operand from there: the 256 registers of query fragments leave
+            // the VGPR file to the accumulators, and no v_accvgpr_read copies in the loop)
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=a"(qh[g][kc]) : "v"(a.q_hi + (size_t)qidx * 128 + 16 * kc + 8 * h) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=a"(ql[g][kc]) : "v"(a.q_lo + (size_t)qidx * 128 + 16 * kc + 8 * h) : "memory");
         }
         cnt[g] = 0;
+        ecnt[g] = 0;
         if constexpr (SAMPLE) {
             thr[g] = -INFINITY;
             lp[g] = nullptr;
@@ -1375,7 +1423,7 @@ __global__ __launch_bounds__(512, 2) void bf_scan_f32_kernel(BfScanF32Args a) {
             lp[g] = a.list + (((size_t)qidx * a.nsplit + split) * 2 + h) * a.caph;
         }
     }
-    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): retire the query loads before any DMA is counted
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // retire the query loads before any DMA is counted
 
     for (int t = 0; t < kRing - 1 && t < nstages; ++t) issue_tile(t);
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
@@ -1407,105 +1455,157 @@ __global__ __launch_bounds__(512, 2) void bf_scan_f32_kernel(BfScanF32Args a) {
                 thr[g] = t8[g][7];
             }
         } else if (__any(m >= thr[g])) {
+            // one entry for the block if this lane has a hit (see hit_mask_f32): the re-rank expands them
+            uint32_t km;
+            if constexpr (MODE == SC_COS) {
+                f32x16 sc;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int pos = row0 + acc_row(i, h);
-                if (score_of(c, i, ax) >= thr[g] && pos < a.n) {
-                    if (cnt[g] < a.caph) lp[g][cnt[g]] = (uint32_t)pos;
-                    cnt[g]++;
-                }
+                for (int i = 0; i < 16; ++i) sc[i] = score_of(c, i, ax);
+                km = hit_mask_f32(sc, thr[g]);
+            } else {
+                km = hit_mask_f32(c, thr[g]);
+            }
+            if (row0 + 32 > a.n) {   // pad rows of the dot / cosine modes score 0: never listed
+                asm volatile("" ::: "memory");   // (a real branch: if-converted, these 60 instructions would run on every hit)
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    if (row0 + acc_row(i, h) >= a.n) km &= ~(0x8000u >> i);
+            }
+            if (km) {
+                if (ecnt[g] < a.caph) lp[g][ecnt[g]] = ((uint32_t)(row0 - r_begin) >> 5 << 16) | km;
+                ecnt[g]++;
+                cnt[g] += __builtin_popcount(km);
             }
         }
     };
 
-    f32x16 pv[QG];            // scores of the previous block (possibly of the previous stage), not yet checked
-    const float* pv_ax = auxr;
+    // The 32-row blocks form ONE software pipeline across block and stage boundaries: K-step s of the stream reads the
+    // fragments of K-step s+2 (the last two steps of a block fetch the first two of the next one, and the next block's
+    // accumulator start values), so no block begins with an exposed LDS round trip.  The stage's counted wait + barrier
+    // sits in its MIDDLE (after block 0): it proves stage t+1 landed before block 1 prefetches from it, and that every
+    // wave is done with stage t-1, whose slot then takes stage t+3.
+    // The LDS reads and their waits are written by hand: the compiler's own s_waitcnt placement uses lgkmcnt(0)
+    // throughout this loop, i.e. every wait also waits for the reads just issued for two steps ahead.  LDS reads return
+    // in order, so "at most 4 outstanding" = the reads of steps kc+1 and kc+2 may still fly while step kc's MFMAs
+    // start.  Each wait names the registers it guards, so that the MFMAs that read them cannot be moved above it.
+    // The MFMAs run group-major (the three products of a group back to back on its accumulator); in a block's last
+    // K-step the scores of group g are checked in the shadow of group g+1's MFMAs, the last group's under the first
+    // MFMAs of the next block: no second set of accumulators.
+    bf16x8 fh[4], fl[4];      // fragment slots: K-step kc of any block uses slot kc % 4
+    f32x4 ini[4];             // start values of the next block (l2: -0.5|b|^2 of its rows)
+    f32x16 acc[QG];
+    const float* pv_ax = auxr;   // aux values / first row of the block whose last group is still unchecked
     int pv_row0 = 0;
     bool have_pv = false;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(lptr_t)smem;
+    auto load_frag = [&](uint32_t rp, int kc) __attribute__((always_inline)) {
+        asm volatile("ds_read_b128 %0, %1" : "=v"(fh[kc % 4]) : "v"(rp + foff[kc]) : "memory");
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fl[kc % 4]) : "v"(rp + foff[kc]), "n"(kHalfBytes) : "memory");
+    };
+    auto load_init = [&](uint32_t ax) __attribute__((always_inline)) {
+        // register 4j+i of half h = row 8j + 4h + i of the block
+        if constexpr (MODE == SC_L2) {
+            asm volatile("ds_read_b128 %0, %1" : "=v"(ini[0]) : "v"(ax) : "memory");
+            asm volatile("ds_read_b128 %0, %1 offset:32" : "=v"(ini[1]) : "v"(ax) : "memory");
+            asm volatile("ds_read_b128 %0, %1 offset:64" : "=v"(ini[2]) : "v"(ax) : "memory");
+            asm volatile("ds_read_b128 %0, %1 offset:96" : "=v"(ini[3]) : "v"(ax) : "memory");
+        }
+    };
+    // K-step kc of group g; first = the block's first step: the accumulator starts from the block's start values (as the
+    // MFMA's C operand: no copies)
+    auto mfma3 = [&](int g, int kc, bool first, const f32x16& iv) __attribute__((always_inline)) {
+        acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[kc % 4], qh[g][kc], first ? iv : acc[g], 0, 0, 0);
+        acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl[kc % 4], qh[g][kc], acc[g], 0, 0, 0);
+        acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[kc % 4], ql[g][kc], acc[g], 0, 0, 0);
+    };
+    auto check = [&](int g, const float* ax, int row0) __attribute__((always_inline)) {
+        float m = fmaxf(score_of(acc[g], 0, ax), score_of(acc[g], 1, ax));
+#pragma unroll
+        for (int i = 2; i < 16; i += 2) m = fmaxf(fmaxf(m, score_of(acc[g], i, ax)), score_of(acc[g], i + 1, ax));
+        finish_check(m, acc[g], g, ax, row0);
+    };
+    constexpr int kInitReads = MODE == SC_L2 ? 4 : 0;
+    const uint32_t ring_a = lds0, aux_a = lds0 + kRing * kStageBytes + 16 * h;   // LDS byte addresses
+    if (nstages > 0) {
+        load_init(aux_a);
+        load_frag(ring_a, 0);
+        load_frag(ring_a, 1);
+    }
     for (int t = 0; t < nstages; ++t) {
-        const char* th_ = ring + (t % kRing) * kStageBytes;   // hi tile; lo tile kHalfBytes behind
+        const uint32_t th_ = ring_a + (t % kRing) * kStageBytes;   // hi tile; lo tile kHalfBytes behind
         const float* axs = auxr + (t % kAuxRing) * BF_BN + 4 * h;
         const int row0 = r_begin + t * stage_rows;
-        // the slot of stage t+3 held stage t-1: every wave passed the barrier that ended stage t-1 after its reads
-        if (t + kRing - 1 < nstages) issue_tile(t + kRing - 1);
+        const bool more = t + 1 < nstages;
 #pragma unroll
         for (int blk = 0; blk < 2; ++blk) {
-            const char* rp = th_ + blk * 32 * 256;
-            f32x16 acc[QG];
-            if constexpr (MODE == SC_L2) {
-                // accumulators start from -0.5|b|^2 of their rows: register 4j+i of half h = row 8j + 4h + i of the block
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const f32x4 v = *reinterpret_cast<const f32x4*>(axs + blk * 32 + 8 * j);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-#pragma unroll
-                        for (int g = 0; g < QG; ++g) acc[g][4 * j + i] = v[i];
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int g = 0; g < QG; ++g) {
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) acc[g][i] = 0.f;
-                }
-            }
-            // fragment reads run two K-steps ahead of the MFMAs that use them
-            bf16x8 fh[3], fl[3];
-#pragma unroll
-            for (int p = 0; p < 2; ++p) {
-                fh[p] = *reinterpret_cast<const bf16x8*>(rp + foff[p]);
-                fl[p] = *reinterpret_cast<const bf16x8*>(rp + kHalfBytes + foff[p]);
-            }
-            float mrun[QG];
-#pragma unroll
-            for (int g = 0; g < QG; ++g) mrun[g] = -INFINITY;
+            const uint32_t rp = th_ + blk * 32 * 256;
+            // the block behind this one: block 1 of this stage, or block 0 of the next stage
+            const uint32_t nrp = blk == 0 ? th_ + 32 * 256 : ring_a + ((t + 1) % kRing) * kStageBytes;
+            const uint32_t nax = blk == 0 ? aux_a + ((t % kAuxRing) * BF_BN + 32) * 4 : aux_a + (((t + 1) % kAuxRing) * BF_BN) * 4;
+            const bool has_next = blk == 0 || more;
 #pragma unroll
             for (int kc = 0; kc < 8; ++kc) {
+                // reads of step kc+2, then the wait for step kc's fragments (+ the start values at kc = 0)
                 if (kc + 2 < 8) {
-                    fh[(kc + 2) % 3] = *reinterpret_cast<const bf16x8*>(rp + foff[kc + 2]);
-                    fl[(kc + 2) % 3] = *reinterpret_cast<const bf16x8*>(rp + kHalfBytes + foff[kc + 2]);
+                    load_frag(rp, kc + 2);
+                    if (kc == 0)
+                        asm volatile("s_waitcnt lgkmcnt(4)"
+                                     : "+v"(fh[0]), "+v"(fl[0]), "+v"(ini[0]), "+v"(ini[1]), "+v"(ini[2]), "+v"(ini[3]));
+                    else
+                        asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(fh[kc % 4]), "+v"(fl[kc % 4]));
+                } else if (has_next) {
+                    if (kc == 6) load_init(nax);
+                    load_frag(nrp, kc + 2 - 8);
+                    // in flight behind step kc's fragments: step 7's (kc = 6 only), the start values, the next block's
+                    if (kInitReads) asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(fh[kc % 4]), "+v"(fl[kc % 4]));
+                    else asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(fh[kc % 4]), "+v"(fl[kc % 4]));
+                } else {
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fh[kc % 4]), "+v"(fl[kc % 4]));
                 }
                 __builtin_amdgcn_sched_barrier(0);
+                if (kc == 0) {
+                    // groups 0 .. QG-2 were checked at the end of the previous block; the last one is checked here,
+                    // under the MFMAs of group 0
+                    f32x16 iv;
 #pragma unroll
-                for (int g = 0; g < QG; ++g) {
-                    acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[kc % 3], qh[g][kc], acc[g], 0, 0, 0);
-                    acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl[kc % 3], qh[g][kc], acc[g], 0, 0, 0);
-                    acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[kc % 3], ql[g][kc], acc[g], 0, 0, 0);
-                }
-                if (have_pv) {
+                    for (int i = 0; i < 16; ++i) iv[i] = MODE == SC_L2 ? ini[i >> 2][i & 3] : 0.f;
+                    mfma3(0, 0, true, iv);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (have_pv) check(QG - 1, pv_ax, pv_row0);
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int g = 0; g < QG; ++g)
-                        mrun[g] = fmaxf(fmaxf(mrun[g], score_of(pv[g], 2 * kc, pv_ax)), score_of(pv[g], 2 * kc + 1, pv_ax));
+                    for (int g = 1; g < QG; ++g) mfma3(g, 0, true, iv);
+                } else if (kc == 7) {
+                    mfma3(0, 7, false, acc[0]);
+#pragma unroll
+                    for (int g = 1; g < QG; ++g) {
+                        mfma3(g, 7, false, acc[0]);
+                        __builtin_amdgcn_sched_barrier(0);
+                        check(g - 1, axs + blk * 32, row0 + blk * 32);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                } else {
+#pragma unroll
+                    for (int g = 0; g < QG; ++g) mfma3(g, kc, false, acc[0]);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (have_pv) {
-#pragma unroll
-                for (int g = 0; g < QG; ++g) finish_check(mrun[g], pv[g], g, pv_ax, pv_row0);
-            }
-#pragma unroll
-            for (int g = 0; g < QG; ++g) pv[g] = acc[g];
             pv_ax = axs + blk * 32;
             pv_row0 = row0 + blk * 32;
             have_pv = true;
-        }
-        // stage t+1 must have landed; stages t+2, t+3 (5 DMA instructions per wave each) may stay in flight
-        if (t + kRing - 1 < nstages) asm volatile("s_waitcnt vmcnt(10)\n\ts_barrier" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-    }
-    if (have_pv) {  // the last block
-#pragma unroll
-        for (int g = 0; g < QG; ++g) {
-            float m = -INFINITY;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) m = fmaxf(m, score_of(pv[g], i, pv_ax));
-            finish_check(m, pv[g], g, pv_ax, pv_row0);
+            if (blk == 0) {
+                // stage t+1 must have landed (stage t+2, kPieces + 1 = 9 DMA instructions per wave, may stay in flight);
+                // behind the barrier no wave reads stage t-1 any more: its slot takes stage t+3
+                if (t + 2 < nstages) asm volatile("s_waitcnt vmcnt(9)\n\ts_barrier" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+                if (t + kRing - 1 < nstages) issue_tile(t + kRing - 1);
+            }
         }
     }
+    if (have_pv) check(QG - 1, pv_ax, pv_row0);  // the last block's last group
 #pragma unroll
     for (int g = 0; g < QG; ++g) {
-        const int qidx = (qt * 8 + wave) * (32 * QG) + g * 32 + l31;
+        const int qidx = (qt * NW + wave) * (32 * QG) + g * 32 + l31;
         if constexpr (SAMPLE) {
             float* o = a.top8 + (((size_t)qidx * a.nsplit + split) * 2 + h) * 8;
 #pragma unroll
@@ -1562,6 +1662,7 @@ struct RerankListF32Args {
     int32_t* out_cnt;
     int* tile_fail;
     int n, k, nsplit, caph, p2max, fail_queries, space, dim, ldb;
+    int tps;                   // tiles per split of the scan (entries hold block indices inside their split)
     const float* queries_sel;  // the queries the selection saw (centred for l2 on un-centred data)
     const float* thr;          // [qpad] selection thresholds (score units)
     float bmax;                // largest row norm of the selection rows
@@ -1615,10 +1716,7 @@ __global__ __launch_bounds__(256) void bf_rerank_f32_list_kernel(RerankListF32Ar
         if (tid == 0) atomicOr(&a.tile_fail[q / a.fail_queries], 1);
         return;
     }
-    for (int idx = tid; idx < nl * a.caph; idx += blockDim.x) {
-        const int s = idx / a.caph, i = idx - s * a.caph;
-        if (i < offs[s + 1] - offs[s]) keys[offs[s] + i] = (u64)a.list[((size_t)q * nl + s) * a.caph + i];
-    }
+    scan_gather_entries(keys, offs, a.list, q, nl, a.caph, a.tps, tid, blockDim.x);
     __syncthreads();
     const int P = next_pow2(total < 2 ? 2 : total);
     const float* qq = a.queries + (size_t)q * a.ldb;
@@ -2286,6 +2384,7 @@ BfU8Fast bf_u8_fast_plan(int n, int nq, int k) {
     if (ns > 256) ns = 256;
     ns = (ns + 7) / 8 * 8;
     if (ns < 8) ns = 8;
+    while ((tiles_all + ns - 1) / ns > 32768) ns += 8;   // list entries hold the 32-row block index inside the split in 16 bits
     f.nsplit = ns;
     f.tps = (tiles_all + ns - 1) / ns;
     const double mean_half = (double)f.r * f.stride / (2.0 * ns);
@@ -2387,6 +2486,7 @@ hipError_t launch_bf_u8_fast(const BfU8Fast& f, int n, int nq, int k, const uint
     r.k = k;
     r.nsplit = f.nsplit;
     r.caph = f.caph;
+    r.tps = f.tps;
     r.p2max = f.p2max;
     r.fail_queries = BF_TQ * f.qg;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(bf_rerank_u8_list_kernel),
@@ -2410,11 +2510,10 @@ BfF32Fast bf_f32_fast_plan(int n, int dim, int nq, int k, int space, bool cosine
     if (const char* e = getenv("NMSLIB_GPU_F32_FAST")) f.use = f.use && atoi(e) != 0;
     if (!f.use) return f;
     f.mode = space == SP_L2 ? 0 : (space == SP_NEGDOT ? 1 : 2);
-    // query groups of 32 per wave: a workgroup (8 waves) serves 256 * qg queries.  Two groups halve the L2 -> LDS
-    // stream and the fragment reads per MFMA but need 256+ VGPRs (both bf16 halves of 64 queries resident): the
-    // compiler spills and the kernel gets slower (0.75 vs 0.68 ms at C2), so one group is the default
-    f.qg = 1;
-    if (const char* e = getenv("NMSLIB_GPU_F32_QG")) f.qg = atoi(e) == 2 ? 2 : 1;
+    // queries per workgroup = 256 * qg: four waves x (2 or 4) groups of 32 (see bf_scan_f32_kernel); the larger shape
+    // halves the L2 -> LDS stream and the LDS reads per MFMA once the batch fills the chip with it
+    f.qg = nq >= 1024 ? 2 : 1;
+    if (const char* e = getenv("NMSLIB_GPU_F32_QG")) f.qg = atoi(e) == 2 ? 2 : (atoi(e) == 1 ? 1 : f.qg);
     const int tq = 256 * f.qg;
     f.qpad = (nq + tq - 1) / tq * tq;
     f.nqt = f.qpad / tq;
@@ -2431,6 +2530,7 @@ BfF32Fast bf_f32_fast_plan(int n, int dim, int nq, int k, int space, bool cosine
     if (ns > 256) ns = 256;
     ns = (ns + 7) / 8 * 8;
     if (ns < 8) ns = 8;
+    while ((tiles_all + ns - 1) / ns > 32768) ns += 8;   // list entries hold the 32-row block index inside the split in 16 bits
     f.nsplit = ns;
     f.tps = (tiles_all + ns - 1) / ns;
     const double mean_half = (double)f.r * f.stride / (2.0 * ns);
@@ -2477,14 +2577,14 @@ static hipError_t launch_scan_f32_one(const BfScanF32Args& a, int grid, size_t l
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bf_scan_f32_kernel<MODE, SAMPLE, QG>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((bf_scan_f32_kernel<MODE, SAMPLE, QG>), dim3(grid), dim3(512), lds, s, a);
+    hipLaunchKernelGGL((bf_scan_f32_kernel<MODE, SAMPLE, QG>), dim3(grid), dim3(256), lds, s, a);
     return hipGetLastError();
 }
 template <int MODE>
 static hipError_t launch_scan_f32_mode(const BfScanF32Args& a, bool sample, int qg, int grid, size_t lds, hipStream_t s) {
-    if (sample) return launch_scan_f32_one<MODE, true, 1>(a, grid, lds, s);   // (the sample pass always with one group)
-    if (qg == 2) return launch_scan_f32_one<MODE, false, 2>(a, grid, lds, s);
-    return launch_scan_f32_one<MODE, false, 1>(a, grid, lds, s);
+    if (sample) return launch_scan_f32_one<MODE, true, 2>(a, grid, lds, s);   // (the sample pass: 256 queries per workgroup)
+    if (qg == 2) return launch_scan_f32_one<MODE, false, 4>(a, grid, lds, s);
+    return launch_scan_f32_one<MODE, false, 2>(a, grid, lds, s);
 }
 
 hipError_t launch_bf_f32_fast(const BfF32Fast& f, int space, int n, int dim, int ldb, int nq, int k, const float* base_orig,
@@ -2551,6 +2651,7 @@ hipError_t launch_bf_f32_fast(const BfF32Fast& f, int space, int n, int dim, int
     r.k = k;
     r.nsplit = f.nsplit;
     r.caph = f.caph;
+    r.tps = f.tps;
     r.p2max = f.p2max;
     r.fail_queries = 256 * f.qg;
     r.space = space;
