@@ -779,9 +779,13 @@ void Engine::finalize() {
                 // largest row norm of the selection rows: the error bound of the split-bf16 score (re-rank proof)
                 DevBuf d_bm;
                 d_bm.ensure(16);
-                hip_check(launch_row_maxnorm(sel_rows, (int)n, ldb_, (int)dim_, d_bm.as<float>(), stream_), "row norms");
-                hip_check(hipMemcpyAsync(&bmax_, d_bm.ptr(), 4, hipMemcpyDeviceToHost, stream_), "bmax");
+                const bool cosine = space_ == SP_COSINE || space_ == SP_ANGULAR;
+                float bm[2] = {0.f, 0.f};
+                hip_check(launch_row_maxnorm(sel_rows, (int)n, ldb_, (int)dim_, cosine, d_bm.as<float>(), stream_), "row norms");
+                hip_check(hipMemcpyAsync(bm, d_bm.ptr(), 8, hipMemcpyDeviceToHost, stream_), "bmax");
                 hip_check(hipStreamSynchronize(stream_), "row norms");
+                bmax_ = bm[0];
+                bres_ = bm[1];
                 have_bf16_ = true;
             }
         }
@@ -1022,11 +1026,11 @@ void Engine::knn_brute(const void* d_queries, size_t nq, size_t k, int32_t* d_id
             ws_cnt_.ensure(bf_cnt_elems(f.fallback) * 4);
             ws_f32_q_.ensure((size_t)f.qpad * 128 * 2 * 2);
             ws_u8_cand_.ensure(bf_f32_top8_elems(f) * 4);
-            ws_u8_thr_.ensure((size_t)f.qpad * 4 + (size_t)f.nqt * 4 + 64);
+            ws_u8_thr_.ensure(bf_f32_thr_bytes(f));
             ws_u8_list_.ensure(bf_f32_list_elems(f) * 4);
             ws_u8_listcnt_.ensure(bf_f32_listcnt_elems(f) * 4);
             float* thr = ws_u8_thr_.as<float>();
-            int* tile_fail = reinterpret_cast<int*>(thr + f.qpad);
+            int* tile_fail = reinterpret_cast<int*>(thr + 2 * (size_t)f.qpad);
             char* qh = ws_f32_q_.as<char>();
             char* ql = qh + (size_t)f.qpad * 128 * 2;
             hipEvent_t eb = nullptr, ee = nullptr;
@@ -1037,7 +1041,7 @@ void Engine::knn_brute(const void* d_queries, size_t nq, size_t k, int32_t* d_id
             }
             hip_check(launch_bf_f32_fast(f, space_, (int)d_n_, dim_eff, ldb, (int)nq, (int)k, d_rows_.as<float>(),
                                          centred_ ? d_rows_sel_.as<float>() : d_rows_.as<float>(), d_aux_.as<float>(),
-                                         d_bf_hi_.ptr(), d_bf_lo_.ptr(), d_auxp_.as<float>(), bmax_, ws_qpad_.as<float>(), qsel, qh, ql,
+                                         d_bf_hi_.ptr(), d_bf_lo_.ptr(), d_auxp_.as<float>(), bmax_, bres_, ws_qpad_.as<float>(), qsel, qh, ql,
                                          ws_u8_cand_.as<float>(), ws_cand_.as<unsigned long long>(), ws_cnt_.as<int>(), thr,
                                          ws_u8_list_.as<uint32_t>(), ws_u8_listcnt_.as<int>(), tile_fail,
                                          d_ids_.as<int32_t>(), d_ids, d_dists, d_cnt, eb, ee, stream),

@@ -236,6 +236,7 @@ class Engine {
     DevBuf d_bf_hi_, d_bf_lo_, d_auxp_, ws_f32_q_;  // f32 fast path: bf16 hi / lo tiles of the selection rows, padded aux, split queries
     bool have_bf16_ = false;
     float bmax_ = 0;  // largest norm of the selection rows
+    float bres_ = 0;  // their largest bf16 rounding residual (relative to the norm for the cosine spaces)
     DevBuf ws_u8_cand_, ws_u8_cnt_, ws_u8_thr_, ws_u8_list_, ws_u8_listcnt_;
     DevBuf d_rows_sel_, d_mean_;  // brute-force L2 on un-centred data: selection copy (rows - column mean) and the mean
     bool centred_ = false;

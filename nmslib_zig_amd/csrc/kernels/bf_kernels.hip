@@ -931,20 +931,22 @@ __global__ __launch_bounds__(256, 2) void bf_select_u8_kernel(BfArgsU8 a) {
 // end of every stage makes all eight waves wait for the slowest, and with ~1 block in 10 holding a hit some wave is on
 // this path in most stages: decoding the mask into row positions there (a divergent loop, or 16 x if-chains) cost
 // 0.09 ms of 0.72 ms at C2.  The re-rank kernels expand the entries (scan_gather_entries).
-// mask bit (15 - i) <=> accumulator register i  (v_cmp + v_addc shift the compare results in from the right)
+// mask bit (15 - i) <=> accumulator register i.  Built without the scalar registers: a compare writes VCC and the
+// instruction that consumes it (v_addc / v_cndmask) waits ~30 clocks for it -- 16 such pairs cost 0.1 ms of 0.65 at C2;
+// the sign of (score - threshold) shifted in with v_alignbit is two plain VALU instructions per score.
+// (score >= t  <=>  score - t is not negative, for all finite values and for infinite scores against finite thresholds;
+//  inf - inf = NaN may add a spurious candidate, never lose one.)
 __device__ __forceinline__ uint32_t hit_mask_f32(const f32x16& c, float t) {
     uint32_t m = 0u;
 #pragma unroll
-    for (int i = 0; i < 16; ++i)
-        asm volatile("v_cmp_ge_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(m) : "v"(c[i]), "v"(t) : "vcc");
-    return m;
+    for (int i = 0; i < 16; ++i) m = __builtin_amdgcn_alignbit(m, __float_as_uint(c[i] - t), 31);   // (m << 1) | sign
+    return ~m & 0xffffu;
 }
 __device__ __forceinline__ uint32_t hit_mask_i32(const i32x16& c, int t) {
     uint32_t m = 0u;
 #pragma unroll
-    for (int i = 0; i < 16; ++i)
-        asm volatile("v_cmp_ge_i32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(m) : "v"(c[i]), "v"(t) : "vcc");
-    return m;
+    for (int i = 0; i < 16; ++i) m = __builtin_amdgcn_alignbit(m, (uint32_t)(c[i] - t), 31);   // scores and thresholds < 2^30
+    return ~m & 0xffffu;
 }
 // list s = (split, half) of query q: entries -> row positions at keys[offs[s] ..]; one thread per list (a handful of
 // entries each).  offs[] holds the prefix sums of the lists' POSITION counts (list_cnt), none above caph here.
@@ -1344,6 +1346,8 @@ struct BfScanF32Args {
     int n, nqt, nsplit, tps, caph;
     int tile_stride;          // SAMPLE
     float* top8;              // SAMPLE: [qpad][nsplit][2][8]
+    const int* group_flag;    // [nqt] or null: a workgroup runs only if group_flag[its query tile] == group_want
+    int group_want;
 };
 
 // Workgroup = 4 waves, ONE per SIMD, each with the SIMD's whole 512-entry register file; a wave serves QG groups of 32
@@ -1362,6 +1366,7 @@ __global__ __launch_bounds__(256) void bf_scan_f32_kernel(BfScanF32Args a) {
     const int qt = rest % a.nqt;
     const int split = (rest / a.nqt) * 8 + xcd;
     if (split >= a.nsplit) return;
+    if (a.group_flag && (a.group_flag[qt] != 0) != (a.group_want != 0)) return;   // the other scan kernel serves this query tile
 
     constexpr int kRing = 4, kAuxRing = 8, kHalfBytes = BF_BN * 256, kStageBytes = 2 * kHalfBytes;  // hi tile | lo tile
     char* ring = smem;
@@ -1492,7 +1497,9 @@ __global__ __launch_bounds__(256) void bf_scan_f32_kernel(BfScanF32Args a) {
     // K-step the scores of group g are checked in the shadow of group g+1's MFMAs, the last group's under the first
     // MFMAs of the next block: no second set of accumulators.
     bf16x8 fh[4], fl[4];      // fragment slots: K-step kc of any block uses slot kc % 4
-    f32x4 ini[4];             // start values of the next block (l2: -0.5|b|^2 of its rows)
+    f32x16 iv;                // start values of the next block (l2: -0.5|b|^2 of its rows; else 0)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) iv[i] = 0.f;
     f32x16 acc[QG];
     const float* pv_ax = auxr;   // aux values / first row of the block whose last group is still unchecked
     int pv_row0 = 0;
@@ -1503,12 +1510,13 @@ __global__ __launch_bounds__(256) void bf_scan_f32_kernel(BfScanF32Args a) {
         asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fl[kc % 4]) : "v"(rp + foff[kc]), "n"(kHalfBytes) : "memory");
     };
     auto load_init = [&](uint32_t ax) __attribute__((always_inline)) {
-        // register 4j+i of half h = row 8j + 4h + i of the block
+        // register 4j+i of half h = row 8j + 4h + i of the block.  The four reads fill ONE 16-register tuple (fixed
+        // registers: inline asm cannot address parts of an operand), which the block's first MFMAs take as C operand
+        // as it stands -- no copies
         if constexpr (MODE == SC_L2) {
-            asm volatile("ds_read_b128 %0, %1" : "=v"(ini[0]) : "v"(ax) : "memory");
-            asm volatile("ds_read_b128 %0, %1 offset:32" : "=v"(ini[1]) : "v"(ax) : "memory");
-            asm volatile("ds_read_b128 %0, %1 offset:64" : "=v"(ini[2]) : "v"(ax) : "memory");
-            asm volatile("ds_read_b128 %0, %1 offset:96" : "=v"(ini[3]) : "v"(ax) : "memory");
+            asm volatile("ds_read_b128 v[240:243], %1\n\tds_read_b128 v[244:247], %1 offset:32\n\t"
+                         "ds_read_b128 v[248:251], %1 offset:64\n\tds_read_b128 v[252:255], %1 offset:96"
+                         : "={v[240:255]}"(iv) : "v"(ax) : "memory");
         }
     };
     // K-step kc of group g; first = the block's first step: the accumulator starts from the block's start values (as the
@@ -1518,11 +1526,25 @@ __global__ __launch_bounds__(256) void bf_scan_f32_kernel(BfScanF32Args a) {
         acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl[kc % 4], qh[g][kc], acc[g], 0, 0, 0);
         acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[kc % 4], ql[g][kc], acc[g], 0, 0, 0);
     };
-    auto check = [&](int g, const float* ax, int row0) __attribute__((always_inline)) {
-        float m = fmaxf(score_of(acc[g], 0, ax), score_of(acc[g], 1, ax));
+    // best score of a lane's 16 (a tree: three dependent steps)
+    auto block_max = [&](int g, const float* ax) __attribute__((always_inline)) -> float {
+        float m[5];
 #pragma unroll
-        for (int i = 2; i < 16; i += 2) m = fmaxf(fmaxf(m, score_of(acc[g], i, ax)), score_of(acc[g], i + 1, ax));
-        finish_check(m, acc[g], g, ax, row0);
+        for (int j = 0; j < 5; ++j)
+            m[j] = fmaxf(fmaxf(score_of(acc[g], 3 * j, ax), score_of(acc[g], 3 * j + 1, ax)), score_of(acc[g], 3 * j + 2, ax));
+        return fmaxf(fmaxf(fmaxf(m[0], m[1]), m[2]), fmaxf(fmaxf(m[3], m[4]), score_of(acc[g], 15, ax)));
+    };
+    // the three MFMAs of (g, kc) with the VALU work that precedes this call in the same block spread into their shadow
+    // (an MFMA holds the matrix pipe 32 clocks; the wave issues ~4 other instructions meanwhile.  A check placed BEHIND
+    // its MFMAs -- a dozen dependent VALU instructions, a compare and a branch -- left the pipe idle ~150 clocks)
+    auto mfma3_over = [&](int g, int kc, bool first) __attribute__((always_inline)) {
+        mfma3(g, kc, first, iv);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
     };
     constexpr int kInitReads = MODE == SC_L2 ? 4 : 0;
     const uint32_t ring_a = lds0, aux_a = lds0 + kRing * kStageBytes + 16 * h;   // LDS byte addresses
@@ -1548,9 +1570,8 @@ __global__ __launch_bounds__(256) void bf_scan_f32_kernel(BfScanF32Args a) {
                 // reads of step kc+2, then the wait for step kc's fragments (+ the start values at kc = 0)
                 if (kc + 2 < 8) {
                     load_frag(rp, kc + 2);
-                    if (kc == 0)
-                        asm volatile("s_waitcnt lgkmcnt(4)"
-                                     : "+v"(fh[0]), "+v"(fl[0]), "+v"(ini[0]), "+v"(ini[1]), "+v"(ini[2]), "+v"(ini[3]));
+                    if (kc == 0 && MODE == SC_L2)
+                        asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(fh[0]), "+v"(fl[0]), "+{v[240:255]}"(iv));
                     else
                         asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(fh[kc % 4]), "+v"(fl[kc % 4]));
                 } else if (has_next) {
@@ -1566,12 +1587,14 @@ __global__ __launch_bounds__(256) void bf_scan_f32_kernel(BfScanF32Args a) {
                 if (kc == 0) {
                     // groups 0 .. QG-2 were checked at the end of the previous block; the last one is checked here,
                     // under the MFMAs of group 0
-                    f32x16 iv;
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) iv[i] = MODE == SC_L2 ? ini[i >> 2][i & 3] : 0.f;
-                    mfma3(0, 0, true, iv);
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (have_pv) check(QG - 1, pv_ax, pv_row0);
+                    if (have_pv) {
+                        const float m = block_max(QG - 1, pv_ax);
+                        mfma3_over(0, 0, true);
+                        __builtin_amdgcn_sched_barrier(0);
+                        finish_check(m, acc[QG - 1], QG - 1, pv_ax, pv_row0);
+                    } else {
+                        mfma3(0, 0, true, iv);
+                    }
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int g = 1; g < QG; ++g) mfma3(g, 0, true, iv);
@@ -1579,9 +1602,11 @@ __global__ __launch_bounds__(256) void bf_scan_f32_kernel(BfScanF32Args a) {
                     mfma3(0, 7, false, acc[0]);
 #pragma unroll
                     for (int g = 1; g < QG; ++g) {
-                        mfma3(g, 7, false, acc[0]);
                         __builtin_amdgcn_sched_barrier(0);
-                        check(g - 1, axs + blk * 32, row0 + blk * 32);
+                        const float m = block_max(g - 1, axs + blk * 32);
+                        mfma3_over(g, 7, false);
+                        __builtin_amdgcn_sched_barrier(0);
+                        finish_check(m, acc[g - 1], g - 1, axs + blk * 32, row0 + blk * 32);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 } else {
@@ -1602,7 +1627,7 @@ __global__ __launch_bounds__(256) void bf_scan_f32_kernel(BfScanF32Args a) {
             }
         }
     }
-    if (have_pv) check(QG - 1, pv_ax, pv_row0);  // the last block's last group
+    if (have_pv) finish_check(block_max(QG - 1, pv_ax), acc[QG - 1], QG - 1, pv_ax, pv_row0);  // the last block's last group
 #pragma unroll
     for (int g = 0; g < QG; ++g) {
         const int qidx = (qt * NW + wave) * (32 * QG) + g * 32 + l31;
@@ -1613,6 +1638,207 @@ __global__ __launch_bounds__(256) void bf_scan_f32_kernel(BfScanF32Args a) {
         } else {
             a.list_cnt[((size_t)qidx * a.nsplit + split) * 2 + h] = cnt[g];
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// The same scan with ONE bf16 product per score (q_hi . b_hi): a third of the MFMAs, half the tile stream.  Its scores
+// carry an error of up to E1 = 2^-7 |q||b| (both operands rounded to 8 significant bits); the threshold kernel hands a
+// query tile to this kernel only when the sample shows that much room -- twice over -- between the score every top-k
+// row must reach and a threshold that still lists few rows (bf_f32_threshold_kernel), and the re-rank proves the
+// outcome with E1 in place of the split product's 2^-14 (bf_rerank_f32_list_kernel).  Tiles without that room (low
+// dimensions, tightly packed neighbours) go through bf_scan_f32_kernel.
+// Four waves, one per SIMD, QG groups of 32 queries each; the 32-row blocks alternate between two sets of
+// accumulators: the scores of block n are checked -- one group every other K-step, its dozen VALU instructions spread
+// under that step's MFMAs -- while block n+1 accumulates into the other set.
+// ---------------------------------------------------------------------------------------
+template <int MODE, int QG>
+__global__ __launch_bounds__(256) void bf_scan_bf16_kernel(BfScanF32Args a) {
+    constexpr int NW = 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, l31 = lane & 31;
+    const int b = blockIdx.x;
+    const int xcd = b & 7, rest = b >> 3;
+    const int qt = rest % a.nqt;
+    const int split = (rest / a.nqt) * 8 + xcd;
+    if (split >= a.nsplit) return;
+    if (a.group_flag && (a.group_flag[qt] != 0) != (a.group_want != 0)) return;
+
+    constexpr int kRing = 4, kAuxRing = 8, kStageBytes = BF_BN * 256;   // hi tile only
+    char* ring = smem;
+    float* auxr = reinterpret_cast<float*>(ring + kRing * kStageBytes);  // [kAuxRing][BN]
+    const int tiles_all = (a.n + BF_BN - 1) / BF_BN;
+    const int nstages = max(0, min(a.tps, tiles_all - split * a.tps));
+    const int r_begin = split * a.tps * BF_BN;
+
+    // one stage = 16 DMA pieces of 1 KiB (4 rows x 256 B): wave w issues pieces 4w .. 4w+3 and 16 of the 64 aux values
+    auto issue_tile = [&](int stage) __attribute__((always_inline)) {
+        const int slot = stage % kRing;
+        const int row0 = r_begin + stage * BF_BN;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const int pj = 4 * wave + jj;
+            const int row = 4 * pj + (lane >> 4);
+            const int c = (lane & 15) ^ (row & 15);
+            const __bf16* src = a.base_hi + (size_t)(row0 + row) * 128 + c * 8;
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(ring + slot * kStageBytes + pj * 1024), 16, 0, 0);
+        }
+        if (lane < 16)
+            __builtin_amdgcn_global_load_lds((gptr_t)(a.auxp + row0 + 16 * wave + lane),
+                                             (lptr_t)(auxr + (stage % kAuxRing) * BF_BN + 16 * wave), 4, 0, 0);
+    };
+
+    bf16x8 qh[QG][8];
+    float thr[QG];
+    int cnt[QG], ecnt[QG];
+    uint32_t* lp[QG];
+#pragma unroll
+    for (int g = 0; g < QG; ++g) {
+        const int qidx = (qt * NW + wave) * (32 * QG) + g * 32 + l31;
+#pragma unroll
+        for (int kc = 0; kc < 8; ++kc)
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=a"(qh[g][kc]) : "v"(a.q_hi + (size_t)qidx * 128 + 16 * kc + 8 * h) : "memory");
+        cnt[g] = 0;
+        ecnt[g] = 0;
+        thr[g] = a.thr[qidx];
+        lp[g] = a.list + (((size_t)qidx * a.nsplit + split) * 2 + h) * a.caph;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (int t = 0; t < kRing - 1 && t < nstages; ++t) issue_tile(t);
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+
+    int foff[8];
+#pragma unroll
+    for (int kc = 0; kc < 8; ++kc) foff[kc] = l31 * 256 + (((kc * 2 + h) ^ (l31 & 15)) * 16);
+
+    auto score_of = [&](const f32x16& c, int i, const float* ax) __attribute__((always_inline)) -> float {
+        if constexpr (MODE == SC_COS) return c[i] * ax[(i & 3) + 8 * (i >> 2)];
+        else return c[i];
+    };
+    auto block_max = [&](const f32x16& c, const float* ax) __attribute__((always_inline)) -> float {
+        float m[5];
+#pragma unroll
+        for (int j = 0; j < 5; ++j)
+            m[j] = fmaxf(fmaxf(score_of(c, 3 * j, ax), score_of(c, 3 * j + 1, ax)), score_of(c, 3 * j + 2, ax));
+        return fmaxf(fmaxf(fmaxf(m[0], m[1]), m[2]), fmaxf(fmaxf(m[3], m[4]), score_of(c, 15, ax)));
+    };
+    // (see bf_scan_f32_kernel)
+    auto finish_check = [&](float m, const f32x16& c, int g, const float* ax, int row0) __attribute__((always_inline)) {
+        if (__any(m >= thr[g])) {
+            uint32_t km;
+            if constexpr (MODE == SC_COS) {
+                f32x16 sc;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) sc[i] = score_of(c, i, ax);
+                km = hit_mask_f32(sc, thr[g]);
+            } else {
+                km = hit_mask_f32(c, thr[g]);
+            }
+            if (row0 + 32 > a.n) {
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    if (row0 + acc_row(i, h) >= a.n) km &= ~(0x8000u >> i);
+            }
+            if (km) {
+                if (ecnt[g] < a.caph) lp[g][ecnt[g]] = ((uint32_t)(row0 - r_begin) >> 5 << 16) | km;
+                ecnt[g]++;
+                cnt[g] += __builtin_popcount(km);
+            }
+        }
+    };
+
+    bf16x8 fh[4];
+    f32x16 iv;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) iv[i] = 0.f;
+    f32x16 acc[2][QG];
+    const float* pv_ax = auxr;
+    int pv_row0 = 0;
+    bool have_pv = false;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(lptr_t)smem;
+    auto load_frag = [&](uint32_t rp, int kc) __attribute__((always_inline)) {
+        asm volatile("ds_read_b128 %0, %1" : "=v"(fh[kc % 4]) : "v"(rp + foff[kc]) : "memory");
+    };
+    auto load_init = [&](uint32_t ax) __attribute__((always_inline)) {
+        if constexpr (MODE == SC_L2) {
+            asm volatile("ds_read_b128 v[240:243], %1\n\tds_read_b128 v[244:247], %1 offset:32\n\t"
+                         "ds_read_b128 v[248:251], %1 offset:64\n\tds_read_b128 v[252:255], %1 offset:96"
+                         : "={v[240:255]}"(iv) : "v"(ax) : "memory");
+        }
+    };
+    constexpr int kInitReads = MODE == SC_L2 ? 4 : 0;
+    const uint32_t ring_a = lds0, aux_a = lds0 + kRing * kStageBytes + 16 * h;
+    if (nstages > 0) {
+        load_init(aux_a);
+        load_frag(ring_a, 0);
+        load_frag(ring_a, 1);
+    }
+    for (int t = 0; t < nstages; ++t) {
+        const uint32_t th_ = ring_a + (t % kRing) * kStageBytes;
+        const float* axs = auxr + (t % kAuxRing) * BF_BN + 4 * h;
+        const int row0 = r_begin + t * BF_BN;
+        const bool more = t + 1 < nstages;
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+            const uint32_t rp = th_ + blk * 32 * 256;
+            const uint32_t nrp = blk == 0 ? th_ + 32 * 256 : ring_a + ((t + 1) % kRing) * kStageBytes;
+            const uint32_t nax = blk == 0 ? aux_a + ((t % kAuxRing) * BF_BN + 32) * 4 : aux_a + (((t + 1) % kAuxRing) * BF_BN) * 4;
+            const bool has_next = blk == 0 || more;
+#pragma unroll
+            for (int kc = 0; kc < 8; ++kc) {
+                // the read of step kc+2, then the wait for step kc's fragment: at most the reads of steps kc+1, kc+2 (and
+                // the next block's start values) stay in flight
+                if (kc + 2 < 8) {
+                    load_frag(rp, kc + 2);
+                    if (kc == 0 && MODE == SC_L2) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(fh[0]), "+{v[240:255]}"(iv));
+                    else asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(fh[kc % 4]));
+                } else if (has_next) {
+                    if (kc == 6) load_init(nax);
+                    load_frag(nrp, kc + 2 - 8);
+                    if (kInitReads) asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(fh[kc % 4]));
+                    else asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(fh[kc % 4]));
+                } else {
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fh[kc % 4]));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                // group gc of the previous block is checked under this step's MFMAs
+                constexpr int kEvery = 8 / QG;
+                const int gc = kc / kEvery;
+                const bool chk = (kc % kEvery) == kEvery - 1;
+                float m = 0.f;
+                if (chk && have_pv) m = block_max(acc[blk ^ 1][gc], pv_ax);
+#pragma unroll
+                for (int g = 0; g < QG; ++g) {
+                    acc[blk][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[kc % 4], qh[g][kc], kc == 0 ? iv : acc[blk][g], 0, 0, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 12 / QG, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (chk && have_pv) finish_check(m, acc[blk ^ 1][gc], gc, pv_ax, pv_row0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            pv_ax = axs + blk * 32;
+            pv_row0 = row0 + blk * 32;
+            have_pv = true;
+            if (blk == 0) {
+                // stage t+1 must have landed (stage t+2: 5 DMA instructions per wave may stay in flight); behind the
+                // barrier no wave reads stage t-1 any more: its slot takes stage t+3
+                if (t + 2 < nstages) asm volatile("s_waitcnt vmcnt(5)\n\ts_barrier" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+                if (t + kRing - 1 < nstages) issue_tile(t + kRing - 1);
+            }
+        }
+    }
+    if (have_pv) {   // the last block (nstages > 0: it was block 1 of its stage)
+#pragma unroll
+        for (int g = 0; g < QG; ++g) finish_check(block_max(acc[1][g], pv_ax), acc[1][g], g, pv_ax, pv_row0);
+    }
+#pragma unroll
+    for (int g = 0; g < QG; ++g) {
+        const int qidx = (qt * NW + wave) * (32 * QG) + g * 32 + l31;
+        a.list_cnt[((size_t)qidx * a.nsplit + split) * 2 + h] = cnt[g];
     }
 }
 
@@ -1632,21 +1858,75 @@ __global__ void split_bf16_kernel(const float* src, int rows, int rows_pad, int 
     }
 }
 
-// r-th best value of the sample -> threshold per query (float scores); one wave per query
-__global__ __launch_bounds__(256) void bf_f32_threshold_kernel(const float* top8, int nlists, int r, int nq, float* thr) {
+// Error bound of the one-product score q_hi . b_hi of one query against any row (first wave of the workgroup; result
+// in every lane):  |q.b - q^.b^| <= |q - q^||b| + |q^||b - b^|  with the ACTUAL rounding residual of this query and the
+// largest residual of the rows (bres; relative to |b| for the cosine score, where bscale = 1), plus the f32 accumulation
+// of the MFMAs.  Typically ~0.4 of the worst case 2^-7 |q||b|.
+__device__ __forceinline__ float one_product_error(const float* qs, int dim, int lane, float bscale, float bres) {
+    float ss = 0.f, rr = 0.f;
+    for (int d = lane; d < dim; d += 64) {
+        const float v = qs[d], w = v - (float)(__bf16)v;
+        ss = fmaf(v, v, ss);
+        rr = fmaf(w, w, rr);
+    }
+    const float qn = sqrtf(wave_sum(ss)), qr = sqrtf(wave_sum(rr));
+    return 1.01f * (qr * bscale + 1.004f * qn * bres) + 2e-5f * qn * bscale;
+}
+
+// Thresholds of one query from the sample (the union of the lanes' top-8 lists, sorted); one workgroup per query.
+//   thr3 = the r-th best sample score: at least k' rows of the whole base reach it (see bf_f32_fast_plan), so the exact
+//          score S_k of the k-th neighbour is >= thr3.  The split-product scan lists the rows that reach it.
+//   thr1 = threshold for the one-product scan, whose scores are off by up to E1 (one_product_error): the first sample
+//          score at least 1.1 E1 below thr3 (unlisted rows then have an exact score < thr1 + E1 < S_k: the re-rank's
+//          proof holds).  If the sample has no such score among its best rcap -- the scores near the top are packed
+//          more tightly than the one-product error -- the query's tile is flagged `precise` and goes through the
+//          split-product scan.
+__global__ __launch_bounds__(256) void bf_f32_threshold_kernel(const float* top8, int nlists, int r, int rcap, int nq,
+                                                               const float* queries_sel, int ldb, int dim, float bscale,
+                                                               float bres, int group_q, int force_precise, float* thr3,
+                                                               float* thr1, int* precise) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     u64* keys = reinterpret_cast<u64*>(smem);
+    __shared__ float s_qn;
     const int q = blockIdx.x, tid = threadIdx.x;
     if (q >= nq) {  // padding queries: nothing passes
-        if (tid == 0) thr[q] = INFINITY;
+        if (tid == 0) {
+            thr3[q] = INFINITY;
+            thr1[q] = INFINITY;
+        }
         return;
     }
     const int total = nlists * 8;
     const int P = next_pow2(total < 2 ? 2 : total);
     for (int i = tid; i < P; i += blockDim.x) keys[i] = i < total ? (u64)(~f32_ord(top8[(size_t)q * total + i])) : ~0ull;
+    if (tid < 64) {
+        const float e1 = one_product_error(queries_sel + (size_t)q * ldb, dim, tid, bscale, bres);
+        if (tid == 0) s_qn = e1;
+    }
     __syncthreads();
     block_bitonic_u64_asc(keys, P, tid, blockDim.x);
-    if (tid == 0) thr[q] = total >= r ? ord_f32(~(uint32_t)keys[r - 1]) : -INFINITY;
+    if (tid == 0) {
+        const float t3 = total >= r ? ord_f32(~(uint32_t)keys[r - 1]) : -INFINITY;
+        thr3[q] = t3;
+        float t1 = t3;
+        bool ok = !force_precise;
+        if (ok && t3 > -INFINITY) {
+            const float need = 1.1f * s_qn;
+            const int jmax = rcap < total ? rcap : total;
+            ok = false;
+            for (int j = r; j <= jmax; ++j) {
+                const float v = ord_f32(~(uint32_t)keys[j - 1]);
+                if (!(v > -INFINITY)) break;
+                if (t3 - v >= need) {
+                    t1 = v;
+                    ok = true;
+                    break;
+                }
+            }
+        }
+        thr1[q] = t1;
+        if (!ok) atomicOr(&precise[q / group_q], 1);
+    }
 }
 
 // exact distances (the reference formula on the ORIGINAL rows) of the listed rows, (distance, position) order, top k;
@@ -1664,8 +1944,11 @@ struct RerankListF32Args {
     int n, k, nsplit, caph, p2max, fail_queries, space, dim, ldb;
     int tps;                   // tiles per split of the scan (entries hold block indices inside their split)
     const float* queries_sel;  // the queries the selection saw (centred for l2 on un-centred data)
-    const float* thr;          // [qpad] selection thresholds (score units)
+    const float* thr;          // [qpad] thresholds of the split-product scan (score units)
+    const float* thr1;         // [qpad] thresholds of the one-product scan
+    const int* precise;        // [query tiles] which scan served the tile (1: split product)
     float bmax;                // largest row norm of the selection rows
+    float bres;                // largest bf16 rounding residual of the selection rows (see row_maxnorm_kernel)
 };
 
 __global__ __launch_bounds__(256) void bf_rerank_f32_list_kernel(RerankListF32Args a) {
@@ -1741,18 +2024,24 @@ __global__ __launch_bounds__(256) void bf_rerank_f32_list_kernel(RerankListF32Ar
     block_bitonic_u64_asc(keys, P, tid, blockDim.x);
     const int found = total < a.k ? total : a.k;
     // PROOF that no unlisted row belongs to the top k.  The selection score of every row carries an error of at most
-    // E = 2^-15 |q||b| (split-bf16 products: the dropped lo.lo term and the two split residues are each <= 2^-18 per
-    // product, f32 accumulation ~2^-19; a factor 2 of margin).  Unlisted rows scored below the threshold T, so their
-    // exact score is below T + E; if the exact score S_k of the k-th result is at least that, every unlisted row is
-    // strictly farther than the k-th result.  Otherwise the adaptive kernel redoes the query's tile group.
+    // E = 2^-14 |q||b|: bf16 rounds to 8 significant bits (relative error <= 2^-8), so the dropped lo.lo product and the
+    // residues of the two splits (x - hi - lo) are each <= 2^-16 |q||b| (Cauchy-Schwarz over the row), their sum
+    // <= 3 * 2^-16, plus the f32 accumulation of the MFMAs (~2^-19).  Unlisted rows scored below the threshold T, so
+    // their exact score is below T + E; if the exact score S_k of the k-th result is at least that, every unlisted row
+    // is strictly farther than the k-th result.  Otherwise the adaptive kernel redoes the query's tile group.
     if (total < a.n) {
-        __shared__ float s_qn2;
+        __shared__ float s_qn2, s_e1;
+        const bool split_product = a.precise[q / a.fail_queries] != 0;
         if (tid < 64) {
             const float* qs = a.queries_sel + (size_t)q * a.ldb;
             float ss = 0.f;
             for (int d = tid; d < a.dim; d += 64) ss = fmaf(qs[d], qs[d], ss);
             ss = wave_sum(ss);
-            if (tid == 0) s_qn2 = ss;
+            const float e1 = split_product ? 0.f : one_product_error(qs, a.dim, tid, a.space == SP_L2 || a.space == SP_NEGDOT ? a.bmax : 1.0f, a.bres);
+            if (tid == 0) {
+                s_qn2 = ss;
+                s_e1 = e1;
+            }
         }
         __syncthreads();
         if (tid == 0) {
@@ -1761,15 +2050,16 @@ __global__ __launch_bounds__(256) void bf_rerank_f32_list_kernel(RerankListF32Ar
             float sk, e;
             if (a.space == SP_L2) {
                 sk = 0.5f * (qn2 - dk * dk);
-                e = 3.0518e-5f * qn * a.bmax;
+                e = 6.1036e-5f * qn * a.bmax;
             } else if (a.space == SP_NEGDOT) {
                 sk = -dk;
-                e = 3.0518e-5f * qn * a.bmax;
+                e = 6.1036e-5f * qn * a.bmax;
             } else {  // cosine / angular: score = q.b / |b| = similarity * |q|
                 sk = (a.space == SP_ANGULAR ? cosf(dk) : 1.0f - dk) * qn;
-                e = 3.0518e-5f * qn;
+                e = 6.1036e-5f * qn;
             }
-            const float t = a.thr[q];
+            const float t = split_product ? a.thr[q] : a.thr1[q];
+            if (!split_product) e = s_e1;   // one bf16 product
             e += 1e-6f * (fabsf(sk) + fabsf(t));  // rounding of sk itself
             if (!(sk - t >= e)) atomicOr(&a.tile_fail[q / a.fail_queries], 1);
         }
@@ -1789,16 +2079,26 @@ __global__ __launch_bounds__(256) void bf_rerank_f32_list_kernel(RerankListF32Ar
     if (tid == 0 && a.out_cnt) a.out_cnt[q] = found;
 }
 
-// largest row norm (atomicMax on the bits of a non-negative float)
-__global__ void row_maxnorm_kernel(const float* rows, int n, int ld, int dim, unsigned* out_bits) {
+// largest row norm -> out[0]; largest bf16 rounding residual |b - bf16(b)| -> out[1] (relative to |b| if `relative`: the
+// cosine score divides by it); atomicMax on the bits of non-negative floats
+__global__ void row_maxnorm_kernel(const float* rows, int n, int ld, int dim, int relative, unsigned* out_bits) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (row >= n) return;
     const float* p = rows + (size_t)row * ld;
-    float s = 0.f;
-    for (int d = lane; d < dim; d += 64) s = fmaf(p[d], p[d], s);
+    float s = 0.f, r = 0.f;
+    for (int d = lane; d < dim; d += 64) {
+        const float v = p[d], w = v - (float)(__bf16)v;
+        s = fmaf(v, v, s);
+        r = fmaf(w, w, r);
+    }
     s = wave_sum(s);
-    if (lane == 0) atomicMax(out_bits, __float_as_uint(sqrtf(s)));
+    r = wave_sum(r);
+    if (lane == 0) {
+        const float nb = sqrtf(s), nr = sqrtf(r);
+        atomicMax(out_bits, __float_as_uint(nb));
+        atomicMax(out_bits + 1, __float_as_uint(relative ? (nb > 0.f ? nr / nb : 0.f) : nr));
+    }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -2524,6 +2824,10 @@ BfF32Fast bf_f32_fast_plan(int n, int dim, int nq, int k, int space, bool cosine
     const int kp = k + (k / 8 > 4 ? k / 8 : 4);
     const double kf = (double)kp / f.stride;
     f.r = (int)(1.6 * kf + 3.0 * sqrt(kf) + 3.0 + 0.999);
+    // the one-product scan may lower its threshold to the rcap-th best sample score to gain room for its error
+    f.rcap = 4 * f.r + 32;
+    f.force_precise = false;
+    if (const char* e = getenv("NMSLIB_GPU_F32_TERMS")) f.force_precise = atoi(e) == 3;
     const int tiles_all = (n + BF_BN - 1) / BF_BN;
     int ns = (256 + f.nqt - 1) / f.nqt;
     if (ns > tiles_all / 16) ns = tiles_all / 16;
@@ -2533,12 +2837,14 @@ BfF32Fast bf_f32_fast_plan(int n, int dim, int nq, int k, int space, bool cosine
     while ((tiles_all + ns - 1) / ns > 32768) ns += 8;   // list entries hold the 32-row block index inside the split in 16 bits
     f.nsplit = ns;
     f.tps = (tiles_all + ns - 1) / ns;
-    const double mean_half = (double)f.r * f.stride / (2.0 * ns);
+    const double mean_half = (double)f.rcap * f.stride / (2.0 * ns);   // (lists sized for the lower threshold)
     int caph = 8;
-    while (caph < 4.0 * mean_half + 8.0) caph <<= 1;
+    while (caph < 3.0 * mean_half + 8.0) caph <<= 1;
     f.caph = caph;
-    f.p2max = host_next_pow2(2 * ns * caph);
+    f.p2max = host_next_pow2((int)(2.5 * f.rcap * f.stride) + 64);      // rows of one query in the re-rank
+    if (f.p2max > 2 * ns * caph) f.p2max = host_next_pow2(2 * ns * caph);
     f.lds_scan = 4 * 2 * BF_BN * 256 + 8 * BF_BN * 4 + 64;
+    f.lds_scan1 = 4 * BF_BN * 256 + 8 * BF_BN * 4 + 64;
     f.lds_rerank = (size_t)f.p2max * 8 + (2 * (size_t)ns + 1) * 4 + 16;
     const int stiles = (tiles_all + f.stride - 1) / f.stride;
     const int s_nqt = f.qpad / 256;
@@ -2554,10 +2860,11 @@ BfF32Fast bf_f32_fast_plan(int n, int dim, int nq, int k, int space, bool cosine
     return f;
 }
 
-hipError_t launch_row_maxnorm(const float* rows, int n, int ld, int dim, float* out, hipStream_t s) {
-    hipError_t e = hipMemsetAsync(out, 0, 4, s);
+hipError_t launch_row_maxnorm(const float* rows, int n, int ld, int dim, bool relative_residual, float* out, hipStream_t s) {
+    hipError_t e = hipMemsetAsync(out, 0, 8, s);
     if (e != hipSuccess || n == 0) return e;
-    hipLaunchKernelGGL(row_maxnorm_kernel, dim3((n + 3) / 4), dim3(256), 0, s, rows, n, ld, dim, reinterpret_cast<unsigned*>(out));
+    hipLaunchKernelGGL(row_maxnorm_kernel, dim3((n + 3) / 4), dim3(256), 0, s, rows, n, ld, dim, relative_residual ? 1 : 0,
+                       reinterpret_cast<unsigned*>(out));
     return hipGetLastError();
 }
 
@@ -2580,26 +2887,39 @@ static hipError_t launch_scan_f32_one(const BfScanF32Args& a, int grid, size_t l
     hipLaunchKernelGGL((bf_scan_f32_kernel<MODE, SAMPLE, QG>), dim3(grid), dim3(256), lds, s, a);
     return hipGetLastError();
 }
+template <int MODE, int QG>
+static hipError_t launch_scan_bf16_one(const BfScanF32Args& a, int grid, size_t lds, hipStream_t s) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bf_scan_bf16_kernel<MODE, QG>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((bf_scan_bf16_kernel<MODE, QG>), dim3(grid), dim3(256), lds, s, a);
+    return hipGetLastError();
+}
+// terms: 3 = the split product (sample pass: always), 1 = one bf16 product
 template <int MODE>
-static hipError_t launch_scan_f32_mode(const BfScanF32Args& a, bool sample, int qg, int grid, size_t lds, hipStream_t s) {
+static hipError_t launch_scan_f32_mode(const BfScanF32Args& a, bool sample, int terms, int qg, int grid, size_t lds, hipStream_t s) {
     if (sample) return launch_scan_f32_one<MODE, true, 2>(a, grid, lds, s);   // (the sample pass: 256 queries per workgroup)
+    if (terms == 1) return qg == 2 ? launch_scan_bf16_one<MODE, 4>(a, grid, lds, s) : launch_scan_bf16_one<MODE, 2>(a, grid, lds, s);
     if (qg == 2) return launch_scan_f32_one<MODE, false, 4>(a, grid, lds, s);
     return launch_scan_f32_one<MODE, false, 2>(a, grid, lds, s);
 }
 
 hipError_t launch_bf_f32_fast(const BfF32Fast& f, int space, int n, int dim, int ldb, int nq, int k, const float* base_orig,
                               const float* sel_rows, const float* aux, const void* base_hi, const void* base_lo,
-                              const float* auxp, float bmax, const float* queries_orig, const float* queries_sel, void* q_hi,
-                              void* q_lo, float* top8, unsigned long long* cand_fb, int* cnt_fb, float* thr,
+                              const float* auxp, float bmax, float bres, const float* queries_orig, const float* queries_sel,
+                              void* q_hi, void* q_lo, float* top8, unsigned long long* cand_fb, int* cnt_fb, float* thr,
                               uint32_t* list, int* list_cnt, int* tile_fail, const int32_t* ext_ids, int32_t* out_ids,
                               float* out_dists, int32_t* out_cnt, hipEvent_t scan_begin, hipEvent_t scan_end,
                               hipStream_t s) {
+    float* thr1 = thr + f.qpad;
+    int* precise = tile_fail + f.nqt;
     hipError_t e = launch_split_bf16(queries_sel, f.qpad, f.qpad, ldb, dim, q_hi, q_lo, nullptr, 0.f, nullptr, s);
     if (e != hipSuccess) return e;
-    auto scan = [&](const BfScanF32Args& sa, bool sample, int grid) -> hipError_t {
-        if (f.mode == 0) return launch_scan_f32_mode<SC_L2>(sa, sample, f.qg, grid, f.lds_scan, s);
-        if (f.mode == 1) return launch_scan_f32_mode<SC_DOT>(sa, sample, f.qg, grid, f.lds_scan, s);
-        return launch_scan_f32_mode<SC_COS>(sa, sample, f.qg, grid, f.lds_scan, s);
+    auto scan = [&](const BfScanF32Args& sa, bool sample, int terms, int grid) -> hipError_t {
+        const size_t lds = terms == 1 ? f.lds_scan1 : f.lds_scan;
+        if (f.mode == 0) return launch_scan_f32_mode<SC_L2>(sa, sample, terms, f.qg, grid, lds, s);
+        if (f.mode == 1) return launch_scan_f32_mode<SC_DOT>(sa, sample, terms, f.qg, grid, lds, s);
+        return launch_scan_f32_mode<SC_COS>(sa, sample, terms, f.qg, grid, lds, s);
     };
     BfScanF32Args a{};
     a.base_hi = static_cast<const __bf16*>(base_hi);
@@ -2609,31 +2929,44 @@ hipError_t launch_bf_f32_fast(const BfF32Fast& f, int space, int n, int dim, int
     a.q_lo = static_cast<const __bf16*>(q_lo);
     a.n = n;
     a.nqt = f.nqt;
-    // 1. sample pass + thresholds
+    // 1. sample pass (split product: near-exact scores) + thresholds + the choice of the scan per query tile
     BfScanF32Args sa = a;
     sa.nqt = f.qpad / 256;
     sa.nsplit = f.s_nsplit;
     sa.tps = f.s_tps;
     sa.tile_stride = f.stride;
     sa.top8 = top8;
-    e = scan(sa, true, 8 * sa.nqt * (f.s_nsplit / 8));
+    e = scan(sa, true, 3, 8 * sa.nqt * (f.s_nsplit / 8));
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(tile_fail, 0, (size_t)f.nqt * 8, s);   // fallback flags + precise flags
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(bf_f32_threshold_kernel),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)f.lds_thr);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(bf_f32_threshold_kernel, dim3(f.qpad), dim3(256), f.lds_thr, s, top8, 2 * f.s_nsplit, f.r, nq, thr);
-    e = hipMemsetAsync(tile_fail, 0, (size_t)f.nqt * 4, s);
+    hipLaunchKernelGGL(bf_f32_threshold_kernel, dim3(f.qpad), dim3(256), f.lds_thr, s, top8, 2 * f.s_nsplit, f.r, f.rcap, nq,
+                       queries_sel, ldb, dim, f.mode == 2 ? 1.0f : bmax, bres, 256 * f.qg, f.force_precise ? 1 : 0, thr,
+                       thr1, precise);
+    e = hipGetLastError();
     if (e != hipSuccess) return e;
-    // 2. scan with fixed thresholds
-    a.thr = thr;
+    // 2. scan with fixed thresholds: every query tile by one of the two kernels (the other's workgroups leave at once)
     a.list = list;
     a.list_cnt = list_cnt;
     a.nsplit = f.nsplit;
     a.tps = f.tps;
     a.caph = f.caph;
     a.tile_stride = 1;
+    a.group_flag = precise;
+    const int grid = 8 * f.nqt * (f.nsplit / 8);
     if (scan_begin) (void)hipEventRecord(scan_begin, s);
-    e = scan(a, false, 8 * f.nqt * (f.nsplit / 8));
+    if (!f.force_precise) {
+        a.thr = thr1;
+        a.group_want = 0;
+        e = scan(a, false, 1, grid);
+        if (e != hipSuccess) return e;
+    }
+    a.thr = thr;
+    a.group_want = 1;
+    e = scan(a, false, 3, grid);
     if (scan_end) (void)hipEventRecord(scan_end, s);
     if (e != hipSuccess) return e;
     // 3. exact re-rank (reference formula, original rows) + verification
@@ -2659,14 +2992,17 @@ hipError_t launch_bf_f32_fast(const BfF32Fast& f, int space, int n, int dim, int
     r.ldb = ldb;
     r.queries_sel = queries_sel;
     r.thr = thr;
+    r.thr1 = thr1;
+    r.precise = precise;
     r.bmax = bmax;
+    r.bres = bres;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(bf_rerank_f32_list_kernel),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)f.lds_rerank);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(bf_rerank_f32_list_kernel, dim3(nq), dim3(256), f.lds_rerank, s, r);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
-    // 4. fallback: the adaptive f32 kernel + its re-rank for flagged 256-query groups (= 2 of its 128-query tiles)
+    // 4. fallback: the adaptive f32 kernel + its re-rank for flagged query tiles (256 * qg queries = 2 * qg of its tiles)
     e = launch_bf_select_f32_ex(f.fallback, space, sel_rows, aux, queries_sel, nullptr, cand_fb, cnt_fb, tile_fail, 2 * f.qg, s);
     if (e != hipSuccess) return e;
     return launch_bf_rerank_ex(f.fallback, space, dim, k, base_orig, queries_orig, cand_fb, cnt_fb, ext_ids, out_ids,

@@ -120,28 +120,33 @@ hipError_t launch_bf_select_f32_ex(const BfPlan& p, int space, const float* base
 struct BfF32Fast {
     bool use;
     int mode;                  // 0 l2, 1 negdotprod, 2 cosine / angular (uncentred)
-    int qg;                    // query groups of 32 per wave (scan): a workgroup serves 256 * qg queries
+    int qg;                    // a scan workgroup serves 256 * qg queries (= one query tile)
     int qpad, nqt;             // queries padded to 256 * qg; scan query tiles
     int stride, r;
+    int rcap;                  // one-product scan: its threshold may sit as low as the rcap-th best sample score
+    bool force_precise;        // NMSLIB_GPU_F32_TERMS=3: every tile through the split-product scan
     int nsplit, tps, caph, p2max;
     int s_nsplit, s_tps;
-    size_t lds_scan, lds_thr, lds_rerank;
+    size_t lds_scan, lds_scan1, lds_thr, lds_rerank;
     BfPlan fallback;
 };
 BfF32Fast bf_f32_fast_plan(int n, int dim, int nq, int k, int space, bool cosine_centred);
+// workspace behind `thr`: [qpad] split-product thresholds, [qpad] one-product thresholds; behind `tile_fail`: [nqt]
+// fallback flags, [nqt] precise flags
+inline size_t bf_f32_thr_bytes(const BfF32Fast& f) { return (size_t)f.qpad * 8 + (size_t)f.nqt * 8 + 64; }
 inline size_t bf_f32_list_elems(const BfF32Fast& f) { return (size_t)f.qpad * f.nsplit * 2 * f.caph; }
 inline size_t bf_f32_listcnt_elems(const BfF32Fast& f) { return (size_t)f.qpad * f.nsplit * 2; }
 inline size_t bf_f32_top8_elems(const BfF32Fast& f) { return (size_t)f.qpad * f.s_nsplit * 2 * 8; }
 inline int bf_f32_rows_padded(int n) { return (n + BF_BN - 1) / BF_BN * BF_BN + BF_BN; }
 // rows (or queries) -> bf16 hi / lo tiles [rows_pad][128]; auxp [rows_pad] = aux, aux_pad behind `rows` (optional)
 // largest row norm -> *out (device float)
-hipError_t launch_row_maxnorm(const float* rows, int n, int ld, int dim, float* out, hipStream_t s);
+hipError_t launch_row_maxnorm(const float* rows, int n, int ld, int dim, bool relative_residual, float* out, hipStream_t s);
 hipError_t launch_split_bf16(const float* src, int rows, int rows_pad, int ld, int dim, void* hi, void* lo,
                              const float* aux, float aux_pad, float* auxp, hipStream_t s);
 hipError_t launch_bf_f32_fast(const BfF32Fast& f, int space, int n, int dim, int ldb, int nq, int k, const float* base_orig,
                               const float* sel_rows, const float* aux, const void* base_hi, const void* base_lo,
-                              const float* auxp, float bmax, const float* queries_orig, const float* queries_sel, void* q_hi,
-                              void* q_lo, float* top8, unsigned long long* cand_fb, int* cnt_fb, float* thr,
+                              const float* auxp, float bmax, float bres, const float* queries_orig, const float* queries_sel,
+                              void* q_hi, void* q_lo, float* top8, unsigned long long* cand_fb, int* cnt_fb, float* thr,
                               uint32_t* list, int* list_cnt, int* tile_fail, const int32_t* ext_ids, int32_t* out_ids,
                               float* out_dists, int32_t* out_cnt, hipEvent_t scan_begin, hipEvent_t scan_end,
                               hipStream_t s);
