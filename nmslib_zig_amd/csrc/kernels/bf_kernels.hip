@@ -1471,10 +1471,13 @@ __global__ __launch_bounds__(256) void bf_scan_f32_kernel(BfScanF32Args a) {
                 km = hit_mask_f32(c, thr[g]);
             }
             if (row0 + 32 > a.n) {   // pad rows of the dot / cosine modes score 0: never listed
-                asm volatile("" ::: "memory");   // (a real branch: if-converted, these 60 instructions would run on every hit)
+                // (behind an opaque copy of the row count: hoisted out of the branch, these 60 instructions would run
+                //  on every check)
+                int nvalid = a.n - row0;
+                asm volatile("" : "+s"(nvalid));
 #pragma unroll
                 for (int i = 0; i < 16; ++i)
-                    if (row0 + acc_row(i, h) >= a.n) km &= ~(0x8000u >> i);
+                    if (acc_row(i, h) >= nvalid) km &= ~(0x8000u >> i);
             }
             if (km) {
                 if (ecnt[g] < a.caph) lp[g][ecnt[g]] = ((uint32_t)(row0 - r_begin) >> 5 << 16) | km;
@@ -1665,7 +1668,10 @@ __global__ __launch_bounds__(256) void bf_scan_bf16_kernel(BfScanF32Args a) {
     if (split >= a.nsplit) return;
     if (a.group_flag && (a.group_flag[qt] != 0) != (a.group_want != 0)) return;
 
-    constexpr int kRing = 4, kAuxRing = 8, kStageBytes = BF_BN * 256;   // hi tile only
+    // hi tile only: 16 KB stages.  The waves meet every kSync stages (a wave that met a hit runs ~200 clocks late; the
+    // fewer meetings, the less of that lateness everyone waits for): ring = the stage being read + kSync landed +
+    // kSync in flight
+    constexpr int kSync = 4, kRing = 2 * kSync + 1, kAuxRing = 16, kStageBytes = BF_BN * 256;
     char* ring = smem;
     float* auxr = reinterpret_cast<float*>(ring + kRing * kStageBytes);  // [kAuxRing][BN]
     const int tiles_all = (a.n + BF_BN - 1) / BF_BN;
@@ -1705,7 +1711,7 @@ __global__ __launch_bounds__(256) void bf_scan_bf16_kernel(BfScanF32Args a) {
         lp[g] = a.list + (((size_t)qidx * a.nsplit + split) * 2 + h) * a.caph;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    for (int t = 0; t < kRing - 1 && t < nstages; ++t) issue_tile(t);
+    for (int t = 0; t <= kSync && t < nstages; ++t) issue_tile(t);
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
 
     int foff[8];
@@ -1736,10 +1742,11 @@ __global__ __launch_bounds__(256) void bf_scan_bf16_kernel(BfScanF32Args a) {
                 km = hit_mask_f32(c, thr[g]);
             }
             if (row0 + 32 > a.n) {
-                asm volatile("" ::: "memory");
+                int nvalid = a.n - row0;
+                asm volatile("" : "+s"(nvalid));
 #pragma unroll
                 for (int i = 0; i < 16; ++i)
-                    if (row0 + acc_row(i, h) >= a.n) km &= ~(0x8000u >> i);
+                    if (acc_row(i, h) >= nvalid) km &= ~(0x8000u >> i);
             }
             if (km) {
                 if (ecnt[g] < a.caph) lp[g][ecnt[g]] = ((uint32_t)(row0 - r_begin) >> 5 << 16) | km;
@@ -1754,6 +1761,11 @@ __global__ __launch_bounds__(256) void bf_scan_bf16_kernel(BfScanF32Args a) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) iv[i] = 0.f;
     f32x16 acc[2][QG];
+#pragma unroll
+    for (int g = 0; g < QG; ++g) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[0][g][i] = acc[1][g][i] = 0.f;
+    }
     const float* pv_ax = auxr;
     int pv_row0 = 0;
     bool have_pv = false;
@@ -1808,7 +1820,7 @@ __global__ __launch_bounds__(256) void bf_scan_bf16_kernel(BfScanF32Args a) {
                 const int gc = kc / kEvery;
                 const bool chk = (kc % kEvery) == kEvery - 1;
                 float m = 0.f;
-                if (chk && have_pv) m = block_max(acc[blk ^ 1][gc], pv_ax);
+                if (chk) m = block_max(acc[blk ^ 1][gc], pv_ax);   // (also before the first block: no branch between the MFMAs)
 #pragma unroll
                 for (int g = 0; g < QG; ++g) {
                     acc[blk][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[kc % 4], qh[g][kc], kc == 0 ? iv : acc[blk][g], 0, 0, 0);
@@ -1823,11 +1835,12 @@ __global__ __launch_bounds__(256) void bf_scan_bf16_kernel(BfScanF32Args a) {
             pv_row0 = row0 + blk * 32;
             have_pv = true;
             if (blk == 0) {
-                // stage t+1 must have landed (stage t+2: 5 DMA instructions per wave may stay in flight); behind the
-                // barrier no wave reads stage t-1 any more: its slot takes stage t+3
-                if (t + 2 < nstages) asm volatile("s_waitcnt vmcnt(5)\n\ts_barrier" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-                if (t + kRing - 1 < nstages) issue_tile(t + kRing - 1);
+                // every kSync stages: the next kSync stages (requested at the last meeting) must have landed; behind the
+                // barrier no wave reads the kSync stages before this one any more: their slots take the next requests
+                if (t % kSync == 0) {
+                    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+                    for (int u = t + kSync + 1; u <= t + 2 * kSync && u < nstages; ++u) issue_tile(u);
+                }
             }
         }
     }
@@ -2083,21 +2096,25 @@ __global__ __launch_bounds__(256) void bf_rerank_f32_list_kernel(RerankListF32Ar
 // cosine score divides by it); atomicMax on the bits of non-negative floats
 __global__ void row_maxnorm_kernel(const float* rows, int n, int ld, int dim, int relative, unsigned* out_bits) {
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (row >= n) return;
-    const float* p = rows + (size_t)row * ld;
-    float s = 0.f, r = 0.f;
-    for (int d = lane; d < dim; d += 64) {
-        const float v = p[d], w = v - (float)(__bf16)v;
-        s = fmaf(v, v, s);
-        r = fmaf(w, w, r);
-    }
-    s = wave_sum(s);
-    r = wave_sum(r);
-    if (lane == 0) {
+    const int wpb = blockDim.x >> 6;
+    float mb = 0.f, mr = 0.f;   // this wave's maxima over its rows: one pair of atomics per wave
+    for (int row = blockIdx.x * wpb + (threadIdx.x >> 6); row < n; row += gridDim.x * wpb) {
+        const float* p = rows + (size_t)row * ld;
+        float s = 0.f, r = 0.f;
+        for (int d = lane; d < dim; d += 64) {
+            const float v = p[d], w = v - (float)(__bf16)v;
+            s = fmaf(v, v, s);
+            r = fmaf(w, w, r);
+        }
+        s = wave_sum(s);
+        r = wave_sum(r);
         const float nb = sqrtf(s), nr = sqrtf(r);
-        atomicMax(out_bits, __float_as_uint(nb));
-        atomicMax(out_bits + 1, __float_as_uint(relative ? (nb > 0.f ? nr / nb : 0.f) : nr));
+        mb = fmaxf(mb, nb);
+        mr = fmaxf(mr, relative ? (nb > 0.f ? nr / nb : 0.f) : nr);
+    }
+    if (lane == 0) {
+        atomicMax(out_bits, __float_as_uint(mb));
+        atomicMax(out_bits + 1, __float_as_uint(mr));
     }
 }
 
@@ -2844,7 +2861,7 @@ BfF32Fast bf_f32_fast_plan(int n, int dim, int nq, int k, int space, bool cosine
     f.p2max = host_next_pow2((int)(2.5 * f.rcap * f.stride) + 64);      // rows of one query in the re-rank
     if (f.p2max > 2 * ns * caph) f.p2max = host_next_pow2(2 * ns * caph);
     f.lds_scan = 4 * 2 * BF_BN * 256 + 8 * BF_BN * 4 + 64;
-    f.lds_scan1 = 4 * BF_BN * 256 + 8 * BF_BN * 4 + 64;
+    f.lds_scan1 = 9 * BF_BN * 256 + 16 * BF_BN * 4 + 64;
     f.lds_rerank = (size_t)f.p2max * 8 + (2 * (size_t)ns + 1) * 4 + 16;
     const int stiles = (tiles_all + f.stride - 1) / f.stride;
     const int s_nqt = f.qpad / 256;
@@ -2863,7 +2880,9 @@ BfF32Fast bf_f32_fast_plan(int n, int dim, int nq, int k, int space, bool cosine
 hipError_t launch_row_maxnorm(const float* rows, int n, int ld, int dim, bool relative_residual, float* out, hipStream_t s) {
     hipError_t e = hipMemsetAsync(out, 0, 8, s);
     if (e != hipSuccess || n == 0) return e;
-    hipLaunchKernelGGL(row_maxnorm_kernel, dim3((n + 3) / 4), dim3(256), 0, s, rows, n, ld, dim, relative_residual ? 1 : 0,
+    int grid = (n + 3) / 4;
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(row_maxnorm_kernel, dim3(grid), dim3(256), 0, s, rows, n, ld, dim, relative_residual ? 1 : 0,
                        reinterpret_cast<unsigned*>(out));
     return hipGetLastError();
 }
