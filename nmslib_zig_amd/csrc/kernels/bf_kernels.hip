@@ -2015,22 +2015,72 @@ __global__ __launch_bounds__(256) void bf_rerank_f32_list_kernel(RerankListF32Ar
     scan_gather_entries(keys, offs, a.list, q, nl, a.caph, a.tps, tid, blockDim.x);
     __syncthreads();
     const int P = next_pow2(total < 2 ? 2 : total);
+    // exact distances: 16 lanes per row, 4 rows per wave and pass, 4 passes requested together -- 64 rows of the query
+    // in flight per workgroup round (the kernel is a chain of memory round trips).  Bit-identical to
+    // wave_exact_distance_f32 (the adaptive path's re-rank; a query must get the same floats whichever path served it):
+    // lane `sub` plays that function's lanes sub, sub+16, sub+32, sub+48 (dimensions v and v + 64 each), adds them in
+    // the order of its xor-32 and xor-16 steps, and the xor 8 / 4 / 2 / 1 steps run across the 16 lanes.
     const float* qq = a.queries + (size_t)q * a.ldb;
-    for (int j0 = wave * 4; j0 < total; j0 += 16) {
-        uint32_t pos[4];
-        const float* rows[4];
+    const int sub = lane & 15, rg = lane >> 4;
+    float qv[8];
+    bool ok[8];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int j = j0 + r < total ? j0 + r : total - 1;
-            pos[r] = (uint32_t)keys[j];
-            rows[r] = a.base + (size_t)pos[r] * a.ldb;
+    for (int c = 0; c < 8; ++c) {
+        const int d = sub + 16 * c;          // c = 0..3: dimension of virtual lane sub + 16c; c = 4..7: the same + 64
+        ok[c] = d < a.dim;
+        qv[c] = ok[c] ? qq[d] : 0.f;
+    }
+    for (int j0 = wave * 16; j0 < total; j0 += 64) {
+        uint32_t pos[4];
+        float xv[4][8];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = j0 + 4 * u + rg;
+            pos[u] = (uint32_t)keys[j < total ? j : total - 1];
+            const float* row = a.base + (size_t)pos[u] * a.ldb + sub;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) xv[u][c] = ok[c] ? row[16 * c] : 0.f;
         }
-        float d[4];
-        wave_exact_distance_f32_x4(a.space, rows, qq, a.dim, lane, d);
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-            if (lane == 0 && j0 + r < total) keys[j0 + r] = ((u64)f32_ord(d[r]) << 32) | pos[r];
+        for (int u = 0; u < 4; ++u) {
+            float p0[4], p1[4], p2[4];   // per virtual lane: the fma chain over dimensions v, v + 64
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                p0[v] = p1[v] = p2[v] = 0.f;
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    if (64 * c >= a.dim) continue;    // (wave_exact_distance_f32 stops at the last 64-chunk)
+                    const float x = xv[u][v + 4 * c], y = qv[v + 4 * c];
+                    if (a.space == SP_L2) {
+                        const float t = x - y;
+                        p0[v] = fmaf(t, t, p0[v]);
+                    } else {
+                        p0[v] = fmaf(x, y, p0[v]);
+                        if (a.space != SP_NEGDOT) {
+                            p1[v] = fmaf(x, x, p1[v]);
+                            p2[v] = fmaf(y, y, p2[v]);
+                        }
+                    }
+                }
+            }
+            auto tree = [&](const float* p) __attribute__((always_inline)) -> float {
+                float s = (p[0] + p[2]) + (p[1] + p[3]);     // xor 32, then xor 16
+#pragma unroll
+                for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+                return s;
+            };
+            const float s0 = tree(p0);
+            float d;
+            if (a.space == SP_L2) d = sqrtf(s0);
+            else if (a.space == SP_NEGDOT) d = -s0;
+            else {
+                const float sim = normdot_finish(s0, tree(p1), tree(p2));
+                d = a.space == SP_ANGULAR ? acosf(sim) : fmaxf(0.0f, 1.0f - sim);
+            }
+            const int j = j0 + 4 * u + rg;
+            if (sub == 0 && j < total) keys[j] = ((u64)f32_ord(d) << 32) | pos[u];
+        }
     }
     for (int i = total + tid; i < P; i += blockDim.x) keys[i] = ~0ull;
     __syncthreads();
