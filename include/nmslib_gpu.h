@@ -80,8 +80,14 @@ typedef struct {
     size_t rows;
     size_t dim;
     size_t shards;         /* row shards behind this handle (index parameter gpu_shards); 1 = single GPU */
-    size_t last_path;      /* selection path of the last brute-force batch: 0 adaptive f32 MFMA, 1 split-bf16 fast path,
+    size_t last_path;      /* selection path of the last brute-force batch: 0 adaptive f32 MFMA, 1 bf16 fast path,
                               2 adaptive int8, 3 int8 fast path; 4 = HNSW */
+    /* fast paths, last slice of the last batch (reading them waits for the stream): query tiles in the slice, tiles the
+       threshold kernel sent through the split-bf16-product scan instead of the one-product scan (float rows only), and
+       tiles whose verification failed and were redone by the adaptive kernel */
+    size_t fast_tiles;
+    size_t fast_tiles_precise;
+    size_t fast_tiles_fallback;
 } nmslib_gpu_stats_t;
 nmslib_error_t nmslib_gpu_get_stats(nmslib_index_handle_t index, nmslib_gpu_stats_t* out);
 

@@ -759,6 +759,19 @@ void Engine::finalize() {
                 hip_check(launch_row_aux_f32(sel_rows, (int)n, ldb_, (int)dim_, space_, d_aux_.as<float>(), stream_),
                           "row aux");
             }
+            // largest norm (and bf16 rounding residual) of the selection rows: the error bounds of the selection scores
+            // (proofs in bf_rerank_kernel and bf_rerank_f32_list_kernel)
+            {
+                DevBuf d_bm;
+                d_bm.ensure(16);
+                const bool cosine = space_ == SP_COSINE || space_ == SP_ANGULAR;
+                float bm[2] = {0.f, 0.f};
+                hip_check(launch_row_maxnorm(sel_rows, (int)n, ldb_, (int)dim_, cosine, d_bm.as<float>(), stream_), "row norms");
+                hip_check(hipMemcpyAsync(bm, d_bm.ptr(), 8, hipMemcpyDeviceToHost, stream_), "bmax");
+                hip_check(hipStreamSynchronize(stream_), "row norms");
+                bmax_ = bm[0];
+                bres_ = bm[1];
+            }
             // fast path (large batches, D <= 128): bf16 hi / lo tiles of the selection rows + padded aux
             have_bf16_ = false;
             d_bf_hi_.release();
@@ -776,16 +789,6 @@ void Engine::finalize() {
                                             space_ == SP_NEGDOT ? nullptr : d_aux_.as<float>(), pad, d_auxp_.as<float>(),
                                             stream_),
                           "split rows");
-                // largest row norm of the selection rows: the error bound of the split-bf16 score (re-rank proof)
-                DevBuf d_bm;
-                d_bm.ensure(16);
-                const bool cosine = space_ == SP_COSINE || space_ == SP_ANGULAR;
-                float bm[2] = {0.f, 0.f};
-                hip_check(launch_row_maxnorm(sel_rows, (int)n, ldb_, (int)dim_, cosine, d_bm.as<float>(), stream_), "row norms");
-                hip_check(hipMemcpyAsync(bm, d_bm.ptr(), 8, hipMemcpyDeviceToHost, stream_), "bmax");
-                hip_check(hipStreamSynchronize(stream_), "row norms");
-                bmax_ = bm[0];
-                bres_ = bm[1];
                 have_bf16_ = true;
             }
         }
@@ -954,6 +957,25 @@ void Engine::knn_device(const void* d_queries, size_t nq, size_t elem_count, siz
     }
 }
 
+void Engine::fast_tile_counts(size_t* tiles, size_t* precise, size_t* fallback) {
+    *tiles = *precise = *fallback = 0;
+    if (!shards_.empty()) {   // row shards: every shard sees the same batch; the first one's counters stand for the handle
+        shards_[0]->fast_tile_counts(tiles, precise, fallback);
+        return;
+    }
+    if ((last_path != 1 && last_path != 3) || !fast_flags_ || fast_nqt_ <= 0) return;
+    std::vector<int> h((size_t)fast_nqt_ * 2, 0);
+    hip_check(hipSetDevice(device_), "hipSetDevice");
+    hip_check(hipStreamSynchronize(stream_), "stats");
+    hip_check(hipMemcpy(h.data(), fast_flags_, (size_t)fast_nqt_ * (fast_has_precise_ ? 2 : 1) * sizeof(int), hipMemcpyDeviceToHost),
+              "stats flags");
+    *tiles = (size_t)fast_nqt_;
+    for (int i = 0; i < fast_nqt_; ++i) {
+        *fallback += h[i] != 0;
+        if (fast_has_precise_) *precise += h[(size_t)fast_nqt_ + i] != 0;
+    }
+}
+
 void Engine::knn_brute(const void* d_queries, size_t nq, size_t k, int32_t* d_ids, float* d_dists, int32_t* d_cnt,
                        hipStream_t stream) {
     have_counters_ = false;
@@ -1004,6 +1026,9 @@ void Engine::knn_brute(const void* d_queries, size_t nq, size_t k, int32_t* d_id
                                         d_ids_.as<int32_t>(), d_ids, d_dists, d_cnt, eb, ee, stream),
                       "bf_u8_fast");
             last_path = 3;
+            fast_flags_ = tile_fail;
+            fast_nqt_ = f.nqt;
+            fast_has_precise_ = false;
             return;
         }
     }
@@ -1027,6 +1052,7 @@ void Engine::knn_brute(const void* d_queries, size_t nq, size_t k, int32_t* d_id
             ws_f32_q_.ensure((size_t)f.qpad * 128 * 2 * 2);
             ws_u8_cand_.ensure(bf_f32_top8_elems(f) * 4);
             ws_u8_thr_.ensure(bf_f32_thr_bytes(f));
+            ws_flags_.ensure((size_t)f.fallback.nqt * 4 + 64);
             ws_u8_list_.ensure(bf_f32_list_elems(f) * 4);
             ws_u8_listcnt_.ensure(bf_f32_listcnt_elems(f) * 4);
             float* thr = ws_u8_thr_.as<float>();
@@ -1043,10 +1069,13 @@ void Engine::knn_brute(const void* d_queries, size_t nq, size_t k, int32_t* d_id
                                          centred_ ? d_rows_sel_.as<float>() : d_rows_.as<float>(), d_aux_.as<float>(),
                                          d_bf_hi_.ptr(), d_bf_lo_.ptr(), d_auxp_.as<float>(), bmax_, bres_, ws_qpad_.as<float>(), qsel, qh, ql,
                                          ws_u8_cand_.as<float>(), ws_cand_.as<unsigned long long>(), ws_cnt_.as<int>(), thr,
-                                         ws_u8_list_.as<uint32_t>(), ws_u8_listcnt_.as<int>(), tile_fail,
+                                         ws_u8_list_.as<uint32_t>(), ws_u8_listcnt_.as<int>(), tile_fail, ws_flags_.as<int>(),
                                          d_ids_.as<int32_t>(), d_ids, d_dists, d_cnt, eb, ee, stream),
                       "bf_f32_fast");
             last_path = 1;
+            fast_flags_ = tile_fail;
+            fast_nqt_ = f.nqt;
+            fast_has_precise_ = true;
             return;
         }
     }
@@ -1080,11 +1109,17 @@ void Engine::knn_brute(const void* d_queries, size_t nq, size_t k, int32_t* d_id
                                               ws_cand_.as<unsigned long long>(), ws_cnt_.as<int>(), stream),
                   "bf_select_direct");
     } else {
-        hip_check(launch_bf_select_f32(p, space_, centred_ ? d_rows_sel_.as<float>() : d_rows_.as<float>(),
-                                       d_aux_.as<float>(), centred_ ? ws_qsel_.as<float>() : ws_qpad_.as<float>(),
-                                       (centred_ && space_ != SP_L2) ? ws_qaux_.as<float>() : nullptr,
-                                       ws_cand_.as<unsigned long long>(), ws_cnt_.as<int>(), stream),
-                  "bf_select_f32");
+        // selection + re-rank in one chain (l2: verified, with the exact tail for tiles of near-duplicates)
+        ws_flags_.ensure((size_t)p.nqt * 4 + 64);
+        hip_check(launch_bf_adaptive_f32(p, space_, dim_eff, (int)k, d_rows_.as<float>(),
+                                         centred_ ? d_rows_sel_.as<float>() : d_rows_.as<float>(), d_aux_.as<float>(),
+                                         ws_qpad_.as<float>(), centred_ ? ws_qsel_.as<float>() : ws_qpad_.as<float>(),
+                                         (centred_ && space_ != SP_L2) ? ws_qaux_.as<float>() : nullptr, bmax_,
+                                         ws_cand_.as<unsigned long long>(), ws_cnt_.as<int>(), ws_flags_.as<int>(),
+                                         d_ids_.as<int32_t>(), d_ids, d_dists, d_cnt, nullptr, 1, stream),
+                  "bf_adaptive_f32");
+        prof_end(stream);
+        return;
     }
     prof_end(stream);
     hip_check(launch_bf_rerank(p, space_, dim_eff, (int)k, d_rows_.ptr(), ws_qpad_.ptr(),

@@ -168,6 +168,11 @@ class Engine {
 
     double upload_seconds = 0, build_seconds = 0;
     int last_path = 0;  // see nmslib_gpu_stats_t
+    // flags of the last fast-path slice (device): [fast_nqt_] fallback flags, then (float rows) [fast_nqt_] precise flags
+    const int* fast_flags_ = nullptr;
+    int fast_nqt_ = 0;
+    bool fast_has_precise_ = false;
+    void fast_tile_counts(size_t* tiles, size_t* precise, size_t* fallback);
     size_t hbm_bytes() const;
 
     std::mutex mu;  // serialises finalize + queries on one index
@@ -238,6 +243,7 @@ class Engine {
     float bmax_ = 0;  // largest norm of the selection rows
     float bres_ = 0;  // their largest bf16 rounding residual (relative to the norm for the cosine spaces)
     DevBuf ws_u8_cand_, ws_u8_cnt_, ws_u8_thr_, ws_u8_list_, ws_u8_listcnt_;
+    DevBuf ws_flags_;   // verified l2 path: query tiles whose proof failed (exact tail)
     DevBuf d_rows_sel_, d_mean_;  // brute-force L2 on un-centred data: selection copy (rows - column mean) and the mean
     bool centred_ = false;
     double mu_norm_ = 0;  // |column mean| (centred cosine scoring)

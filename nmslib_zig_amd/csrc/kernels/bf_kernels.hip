@@ -26,7 +26,7 @@
 
 namespace gfxknn {
 
-enum BfMode : int { BF_L2 = 0, BF_DOT = 1, BF_COS = 2, BF_L1 = 3, BF_LINF = 4, BF_COSC = 5 };
+enum BfMode : int { BF_L2 = 0, BF_DOT = 1, BF_COS = 2, BF_L1 = 3, BF_LINF = 4, BF_COSC = 5, BF_L2D = 6 };  // L2D: sum (a-b)^2 by VALU
 
 struct BfArgs {
     const float* base;
@@ -237,7 +237,7 @@ __global__ __launch_bounds__(256, 2) void bf_select_f32_kernel(BfArgs a) {
     if (split >= a.nsplit) return;
     if (a.tile_fail && a.tile_fail[qt / a.fail_group] == 0) return;
 
-    constexpr bool kDirect = (MODE == BF_L1 || MODE == BF_LINF);
+    constexpr bool kDirect = (MODE == BF_L1 || MODE == BF_LINF || MODE == BF_L2D);
     constexpr bool kDelay = !kDirect;  // epilogue of stage s overlapped with the MFMAs of s+1
     // BF_COSC = cosine / angular on data with a large common offset: the tile holds CENTRED rows b' = b - mu and the
     // score is -(1 - cos)|q| rebuilt from small quantities only,
@@ -563,9 +563,14 @@ __global__ __launch_bounds__(256, 2) void bf_select_f32_kernel(BfArgs a) {
                         const f32x4 ahi = *reinterpret_cast<const f32x4*>(ap + 8 * tt + 4);
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
-                            const float d0 = fabsf(alo[j] - qlo[tt][j]);
-                            const float d1 = fabsf(ahi[j] - qhi[tt][j]);
-                            s = (MODE == BF_L1) ? (s + d0) + d1 : fmaxf(fmaxf(s, d0), d1);
+                            if constexpr (MODE == BF_L2D) {   // the reference's own form: differences first (no cancellation)
+                                const float t0 = alo[j] - qlo[tt][j], t1 = ahi[j] - qhi[tt][j];
+                                s = fmaf(t1, t1, fmaf(t0, t0, s));
+                            } else {
+                                const float d0 = fabsf(alo[j] - qlo[tt][j]);
+                                const float d1 = fabsf(ahi[j] - qhi[tt][j]);
+                                s = (MODE == BF_L1) ? (s + d0) + d1 : fmaxf(fmaxf(s, d0), d1);
+                            }
                         }
                     }
                 }
@@ -1894,7 +1899,9 @@ __device__ __forceinline__ float one_product_error(const float* qs, int dim, int
 //          proof holds).  If the sample has no such score among its best rcap -- the scores near the top are packed
 //          more tightly than the one-product error -- the query's tile is flagged `precise` and goes through the
 //          split-product scan.
-__global__ __launch_bounds__(256) void bf_f32_threshold_kernel(const float* top8, int nlists, int r, int rcap, int nq,
+// Only the `depth` best of each lane's eight enter the sort (a lane holds 1/nlists of the sample: more than four of the
+// best rcap in one lane is rare, and a dropped value only lowers a threshold).
+__global__ __launch_bounds__(256) void bf_f32_threshold_kernel(const float* top8, int nlists, int depth, int r, int rcap, int nq,
                                                                const float* queries_sel, int ldb, int dim, float bscale,
                                                                float bres, int group_q, int force_precise, float* thr3,
                                                                float* thr1, int* precise) {
@@ -1909,9 +1916,12 @@ __global__ __launch_bounds__(256) void bf_f32_threshold_kernel(const float* top8
         }
         return;
     }
-    const int total = nlists * 8;
+    const int total = nlists * depth;
     const int P = next_pow2(total < 2 ? 2 : total);
-    for (int i = tid; i < P; i += blockDim.x) keys[i] = i < total ? (u64)(~f32_ord(top8[(size_t)q * total + i])) : ~0ull;
+    for (int i = tid; i < P; i += blockDim.x) {
+        const int l = i / depth, j = i - l * depth;
+        keys[i] = i < total ? (u64)(~f32_ord(top8[((size_t)q * nlists + l) * 8 + j])) : ~0ull;
+    }
     if (tid < 64) {
         const float e1 = one_product_error(queries_sel + (size_t)q * ldb, dim, tid, bscale, bres);
         if (tid == 0) s_qn = e1;
@@ -2184,6 +2194,12 @@ struct RerankArgs {
     int space, dim, ldb, k, nsplit, cap, kprime, p2max;
     const int* tile_fail;  // u8 fast path fallback: only queries of flagged groups are redone
     int fail_queries;
+    // l2 verification (bf_select_f32_kernel<BF_L2> scores rows by -0.5|b|^2 + q.b: cancellation): see the proof below
+    int* verify_flags;         // [ceil(nq / verify_queries)] or null
+    int verify_queries;
+    const float* queries_sel;  // the queries the selection saw
+    float bmax;                // largest norm of the selection rows
+    float eps_rel;             // error of a selection score relative to |q||b|max + |b|max^2 / 2
 };
 
 __global__ __launch_bounds__(256) void bf_rerank_kernel(RerankArgs a) {
@@ -2205,11 +2221,27 @@ __global__ __launch_bounds__(256) void bf_rerank_kernel(RerankArgs a) {
     __syncthreads();
     const int total = offs[a.nsplit];
     // gather survivor positions (low word of keys[] used as a temporary list)
+    __shared__ uint32_t s_kth;   // verification: the k'-th best SELECTION score among the survivors (ordered bits)
+    const bool verify = a.verify_flags != nullptr && a.space == SP_L2 && total >= a.kprime;
+    if (tid == 0) s_kth = 0xffffffffu;
     for (int idx = tid; idx < a.nsplit * a.kprime; idx += blockDim.x) {
         const int s = idx / a.kprime, i = idx - s * a.kprime;
         const int c = offs[s + 1] - offs[s];
-        if (i < c) keys[offs[s] + i] = (u64)sel_key_pos(a.cand[((size_t)q * a.nsplit + s) * a.cap + i]);
+        if (i < c) keys[offs[s] + i] = a.cand[((size_t)q * a.nsplit + s) * a.cap + i];
     }
+    __syncthreads();
+    if (verify) {
+        // every unlisted row scored at most K' = the k'-th best selection score of the survivors: a split that is full
+        // holds k' survivors at or above its own cut, and the shared threshold never exceeds the k'-th best overall
+        for (int i = tid; i < total; i += blockDim.x) {
+            const uint32_t si = (uint32_t)(keys[i] >> 32);
+            int above = 0;
+            for (int j = 0; j < total; ++j) above += (uint32_t)(keys[j] >> 32) > si;
+            if (above < a.kprime) atomicMin(&s_kth, si);
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < total; i += blockDim.x) keys[i] = (u64)sel_key_pos(keys[i]);
     __syncthreads();
     const int P = next_pow2(total < 2 ? 2 : total);
     if (a.space != SP_L2SQR_SIFT && a.dim <= 256) {
@@ -2268,6 +2300,30 @@ __global__ __launch_bounds__(256) void bf_rerank_kernel(RerankArgs a) {
         a.out_dists[(size_t)q * a.k + i] = d;
     }
     if (tid == 0 && a.out_cnt) a.out_cnt[q] = found;
+    if (verify && found > 0) {
+        // PROOF that no unlisted row belongs to the top k.  The selection scored rows by s^ = -0.5|b|^2 + q.b in f32 (the
+        // MFMA's accumulation): |s^ - s| <= E = eps_rel (|q||b|max + |b|max^2 / 2).  Unlisted rows: s^ <= K', so their
+        // exact squared distance |q|^2 - 2s is at least |q|^2 - 2K' - 2E.  If the k-th result's exact squared distance
+        // is below that, it is closer than every unlisted row.  Otherwise -- more than k' - k rows within 2E of the k-th,
+        // near-duplicates -- the tile is redone with the reference's own form, sum (a-b)^2 (BF_L2D).
+        __shared__ float s_qn2v;
+        if (tid < 64) {
+            const float* qs = a.queries_sel + (size_t)q * a.ldb;
+            float ss = 0.f;
+            for (int d = tid; d < a.dim; d += 64) ss = fmaf(qs[d], qs[d], ss);
+            ss = wave_sum(ss);
+            if (tid == 0) s_qn2v = ss;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            const float qn2 = s_qn2v, qn = sqrtf(qn2);
+            const float kth = ord_f32(s_kth);
+            const float dk = ord_f32((uint32_t)(keys[found - 1] >> 32));
+            const float e = a.eps_rel * (qn * a.bmax + 0.5f * a.bmax * a.bmax);
+            const float floor_d2 = qn2 - 2.0f * kth - 2.0f * e - 2e-6f * (qn2 + fabsf(kth));
+            if (!(dk * dk <= floor_d2)) atomicOr(&a.verify_flags[q / a.verify_queries], 1);
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -2571,7 +2627,7 @@ static hipError_t launch_select_mode(const BfPlan& p, const BfArgs& a, hipStream
     if (MODE == BF_L2 && p.ldb == BF_KC) return launch_select_kern<BF_L2, true, true>(p, a, s);
     return hipErrorInvalidValue;
 #else
-    if constexpr (MODE == BF_L1 || MODE == BF_LINF) {
+    if constexpr (MODE == BF_L1 || MODE == BF_LINF || MODE == BF_L2D) {
         // VALU-bound modes: one generic instantiation is enough (and keeps the build short)
         return launch_select_kern<MODE, false, false>(p, a, s);
     } else {
@@ -2642,12 +2698,22 @@ hipError_t launch_bf_select_f32_ex(const BfPlan& p, int space, const float* base
 hipError_t launch_bf_select_direct_f32(const BfPlan& p, int space, const float* base,
                                        const float* queries_padded, unsigned long long* cand,
                                        int* cand_cnt, hipStream_t s) {
+    return launch_bf_select_direct_f32_ex(p, space, base, queries_padded, cand, cand_cnt, nullptr, 1, s);
+}
+
+// SP_L2 here = squared differences summed by the VALU on the ORIGINAL rows (the exact tail of the verified l2 path)
+hipError_t launch_bf_select_direct_f32_ex(const BfPlan& p, int space, const float* base, const float* queries_padded,
+                                          unsigned long long* cand, int* cand_cnt, const int* tile_fail, int fail_group,
+                                          hipStream_t s) {
     uint32_t* gthr = reinterpret_cast<uint32_t*>(cand_cnt + (size_t)p.qpad * p.nsplit);
     hipError_t me = hipMemsetAsync(gthr, 0, ((size_t)p.qpad + (size_t)p.qpad * p.nsplit) * 4, s);
     if (me != hipSuccess) return me;
     BfArgs a = make_args(p, base, nullptr, queries_padded, cand, cand_cnt, gthr);
+    a.tile_fail = tile_fail;
+    a.fail_group = fail_group;
     if (space == SP_L1) return launch_select_mode<BF_L1>(p, a, s);
     if (space == SP_LINF) return launch_select_mode<BF_LINF>(p, a, s);
+    if (space == SP_L2) return launch_select_mode<BF_L2D>(p, a, s);
     return hipErrorInvalidValue;
 }
 
@@ -2704,7 +2770,21 @@ hipError_t launch_bf_rerank_ex(const BfPlan& p, int space, int dim, int k, const
                                const int* cand_cnt, const int32_t* ext_ids, int32_t* out_ids,
                                float* out_dists, int32_t* out_cnt, const int* tile_fail, int fail_queries,
                                hipStream_t s) {
+    return launch_bf_rerank_verify(p, space, dim, k, base, queries_padded, cand, cand_cnt, ext_ids, out_ids, out_dists,
+                                   out_cnt, tile_fail, fail_queries, nullptr, nullptr, 0.f, s);
+}
+
+hipError_t launch_bf_rerank_verify(const BfPlan& p, int space, int dim, int k, const void* base,
+                                   const void* queries_padded, const unsigned long long* cand,
+                                   const int* cand_cnt, const int32_t* ext_ids, int32_t* out_ids,
+                                   float* out_dists, int32_t* out_cnt, const int* tile_fail, int fail_queries,
+                                   int* verify_flags, const float* queries_sel, float bmax, hipStream_t s) {
     RerankArgs a{};
+    a.verify_flags = verify_flags;
+    a.verify_queries = BF_TQ;
+    a.queries_sel = queries_sel;
+    a.bmax = bmax;
+    a.eps_rel = 1.5f * (float)(dim + 2) * 5.9604645e-8f;   // (D + 2) roundings of 2^-24, half again for the aux term
     a.tile_fail = tile_fail;
     a.fail_queries = fail_queries;
     a.base = base;
@@ -2728,6 +2808,31 @@ hipError_t launch_bf_rerank_ex(const BfPlan& p, int space, int dim, int k, const
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(bf_rerank_kernel, dim3(p.nq), dim3(256), p.lds_rerank, s, a);
     return hipGetLastError();
+}
+
+// The adaptive f32 selection + re-rank, verified for l2 (see bf_rerank_kernel), with the exact tail: tiles whose proof
+// fails are selected again by BF_L2D on the original rows.  `gate` / gate_tiles: run only the query-tile groups flagged
+// by an earlier stage (the fast paths' fallback), or null.  flags: [p.nqt] ints of workspace.
+hipError_t launch_bf_adaptive_f32(const BfPlan& p, int space, int dim, int k, const float* base_orig, const float* sel_rows,
+                                  const float* aux, const float* queries_orig, const float* queries_sel,
+                                  const float* qaux_cosc, float bmax, unsigned long long* cand, int* cand_cnt, int* flags,
+                                  const int32_t* ext_ids, int32_t* out_ids, float* out_dists, int32_t* out_cnt,
+                                  const int* gate, int gate_tiles, hipStream_t s) {
+    hipError_t e = launch_bf_select_f32_ex(p, space, sel_rows, aux, queries_sel, qaux_cosc, cand, cand_cnt, gate, gate_tiles, s);
+    if (e != hipSuccess) return e;
+    const bool verify = space == SP_L2 && flags != nullptr && bmax > 0.f;
+    if (!verify)
+        return launch_bf_rerank_ex(p, space, dim, k, base_orig, queries_orig, cand, cand_cnt, ext_ids, out_ids, out_dists,
+                                   out_cnt, gate, gate_tiles * BF_TQ, s);
+    e = hipMemsetAsync(flags, 0, (size_t)p.nqt * 4, s);
+    if (e != hipSuccess) return e;
+    e = launch_bf_rerank_verify(p, space, dim, k, base_orig, queries_orig, cand, cand_cnt, ext_ids, out_ids, out_dists,
+                                out_cnt, gate, gate_tiles * BF_TQ, flags, queries_sel, bmax, s);
+    if (e != hipSuccess) return e;
+    e = launch_bf_select_direct_f32_ex(p, SP_L2, base_orig, queries_orig, cand, cand_cnt, flags, 1, s);
+    if (e != hipSuccess) return e;
+    return launch_bf_rerank_ex(p, space, dim, k, base_orig, queries_orig, cand, cand_cnt, ext_ids, out_ids, out_dists,
+                               out_cnt, flags, BF_TQ, s);
 }
 
 // ---- uint8 fast path (see bf_scan_u8_kernel) ----------------------------------------------------------------
@@ -2977,9 +3082,9 @@ hipError_t launch_bf_f32_fast(const BfF32Fast& f, int space, int n, int dim, int
                               const float* sel_rows, const float* aux, const void* base_hi, const void* base_lo,
                               const float* auxp, float bmax, float bres, const float* queries_orig, const float* queries_sel,
                               void* q_hi, void* q_lo, float* top8, unsigned long long* cand_fb, int* cnt_fb, float* thr,
-                              uint32_t* list, int* list_cnt, int* tile_fail, const int32_t* ext_ids, int32_t* out_ids,
-                              float* out_dists, int32_t* out_cnt, hipEvent_t scan_begin, hipEvent_t scan_end,
-                              hipStream_t s) {
+                              uint32_t* list, int* list_cnt, int* tile_fail, int* flags_fb, const int32_t* ext_ids,
+                              int32_t* out_ids, float* out_dists, int32_t* out_cnt, hipEvent_t scan_begin,
+                              hipEvent_t scan_end, hipStream_t s) {
     float* thr1 = thr + f.qpad;
     int* precise = tile_fail + f.nqt;
     hipError_t e = launch_split_bf16(queries_sel, f.qpad, f.qpad, ldb, dim, q_hi, q_lo, nullptr, 0.f, nullptr, s);
@@ -3012,7 +3117,8 @@ hipError_t launch_bf_f32_fast(const BfF32Fast& f, int space, int n, int dim, int
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(bf_f32_threshold_kernel),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)f.lds_thr);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(bf_f32_threshold_kernel, dim3(f.qpad), dim3(256), f.lds_thr, s, top8, 2 * f.s_nsplit, f.r, f.rcap, nq,
+    hipLaunchKernelGGL(bf_f32_threshold_kernel, dim3(f.qpad), dim3(256), f.lds_thr, s, top8, 2 * f.s_nsplit,
+                       f.rcap <= 64 && f.s_nsplit >= 32 ? 4 : 8, f.r, f.rcap, nq,
                        queries_sel, ldb, dim, f.mode == 2 ? 1.0f : bmax, bres, 256 * f.qg, f.force_precise ? 1 : 0, thr,
                        thr1, precise);
     e = hipGetLastError();
@@ -3071,11 +3177,10 @@ hipError_t launch_bf_f32_fast(const BfF32Fast& f, int space, int n, int dim, int
     hipLaunchKernelGGL(bf_rerank_f32_list_kernel, dim3(nq), dim3(256), f.lds_rerank, s, r);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
-    // 4. fallback: the adaptive f32 kernel + its re-rank for flagged query tiles (256 * qg queries = 2 * qg of its tiles)
-    e = launch_bf_select_f32_ex(f.fallback, space, sel_rows, aux, queries_sel, nullptr, cand_fb, cnt_fb, tile_fail, 2 * f.qg, s);
-    if (e != hipSuccess) return e;
-    return launch_bf_rerank_ex(f.fallback, space, dim, k, base_orig, queries_orig, cand_fb, cnt_fb, ext_ids, out_ids,
-                               out_dists, out_cnt, tile_fail, 256 * f.qg, s);
+    // 4. fallback: the adaptive f32 kernel + its re-rank (verified for l2, with its exact tail) for flagged query tiles
+    //    (256 * qg queries = 2 * qg of its tiles)
+    return launch_bf_adaptive_f32(f.fallback, space, dim, k, base_orig, sel_rows, aux, queries_orig, queries_sel, nullptr, bmax,
+                                  cand_fb, cnt_fb, flags_fb, ext_ids, out_ids, out_dists, out_cnt, tile_fail, 2 * f.qg, s);
 }
 
 hipError_t launch_row_aux_f32(const float* base, int n, int ldb, int dim, int space, float* aux,

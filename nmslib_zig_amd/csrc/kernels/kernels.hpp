@@ -147,10 +147,24 @@ hipError_t launch_bf_f32_fast(const BfF32Fast& f, int space, int n, int dim, int
                               const float* sel_rows, const float* aux, const void* base_hi, const void* base_lo,
                               const float* auxp, float bmax, float bres, const float* queries_orig, const float* queries_sel,
                               void* q_hi, void* q_lo, float* top8, unsigned long long* cand_fb, int* cnt_fb, float* thr,
-                              uint32_t* list, int* list_cnt, int* tile_fail, const int32_t* ext_ids, int32_t* out_ids,
+                              uint32_t* list, int* list_cnt, int* tile_fail, int* flags_fb, const int32_t* ext_ids, int32_t* out_ids,
                               float* out_dists, int32_t* out_cnt, hipEvent_t scan_begin, hipEvent_t scan_end,
                               hipStream_t s);
 
+// The adaptive f32 path end to end (selection, re-rank; l2: verification + exact tail).  flags: [p.nqt] ints.
+hipError_t launch_bf_adaptive_f32(const BfPlan& p, int space, int dim, int k, const float* base_orig, const float* sel_rows,
+                                  const float* aux, const float* queries_orig, const float* queries_sel,
+                                  const float* qaux_cosc, float bmax, unsigned long long* cand, int* cand_cnt, int* flags,
+                                  const int32_t* ext_ids, int32_t* out_ids, float* out_dists, int32_t* out_cnt,
+                                  const int* gate, int gate_tiles, hipStream_t s);
+hipError_t launch_bf_rerank_verify(const BfPlan& p, int space, int dim, int k, const void* base,
+                                   const void* queries_padded, const unsigned long long* cand,
+                                   const int* cand_cnt, const int32_t* ext_ids, int32_t* out_ids,
+                                   float* out_dists, int32_t* out_cnt, const int* tile_fail, int fail_queries,
+                                   int* verify_flags, const float* queries_sel, float bmax, hipStream_t s);
+hipError_t launch_bf_select_direct_f32_ex(const BfPlan& p, int space, const float* base, const float* queries_padded,
+                                          unsigned long long* cand, int* cand_cnt, const int* tile_fail, int fail_group,
+                                          hipStream_t s);
 // Direct (VALU) selection for spaces with no inner-product form (l1, linf).
 hipError_t launch_bf_select_direct_f32(const BfPlan& p, int space, const float* base,
                                        const float* queries_padded, unsigned long long* cand,

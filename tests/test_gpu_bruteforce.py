@@ -3,6 +3,8 @@
 inputs, (3) size-independent properties at BASELINE sizes, (4) the reference's edge cases."""
 import ctypes as C
 
+import os
+
 import numpy as np
 import pytest
 
@@ -389,6 +391,106 @@ def test_f32_fast_path_large_batch(space, D, offset):
     ids2, ds2, _ = idx.knnQueryBatch(Q[:64], k)
     assert (ids2 == ids[:64]).mean() >= 0.999
     assert close_rel(ds2, ds[:64])
+    idx.close()
+
+
+@pytest.mark.parametrize("space", ["l2", "cosinesimil", "negdotprod"])
+def test_f32_fast_path_one_product_scan_chosen_and_proved(space, monkeypatch):
+    """128-D gaussian rows leave room between the top-k scores and a sample threshold for the error of ONE bf16 product
+    (2^-7 |q||b| at worst, bounded per query from its actual rounding residual): every query tile goes through
+    bf_scan_bf16_kernel, the re-rank's proof holds (no fallback tile), and the answers are the ones of the split-product
+    scan (NMSLIB_GPU_F32_TERMS=3) bit for bit -- both end in the same exact re-rank -- and the oracle's."""
+    n, nq, k = 80000, 1024, 10
+    X, Q = refio.s_gauss(n, 128, 171), refio.s_gauss(nq, 128, 172)
+    idx = make_index(space, "seq_search", X)
+    ids, ds, cnt = idx.knnQueryBatch(Q, k)
+    st = idx.stats()
+    assert st["last_path"] == 1 and st["fast_tiles"] == 2, st
+    assert st["fast_tiles_precise"] == 0 and st["fast_tiles_fallback"] == 0, st
+    monkeypatch.setenv("NMSLIB_GPU_F32_TERMS", "3")
+    ids3, ds3, _ = idx.knnQueryBatch(Q, k)
+    st3 = idx.stats()
+    assert st3["fast_tiles_precise"] == 2 and st3["fast_tiles_fallback"] == 0, st3
+    monkeypatch.delenv("NMSLIB_GPU_F32_TERMS")
+    np.testing.assert_array_equal(ids, ids3)
+    np.testing.assert_array_equal(ds, ds3)
+    sel = np.r_[0:16, nq - 16:nq]
+    opos, odist, _ = orc.seq_search(space, X, Q[sel], k + 22)
+    assert refio.recall_nmslib(ids[sel], opos, odist, k) >= 0.999
+    assert close_rel(ds[sel], odist[:, :k], rtol=1e-5, atol=1e-6)
+    idx.close()
+
+
+def test_f32_fast_path_tight_scores_take_the_split_product_scan():
+    """negdotprod on rows c + 1e-3 g with |c| = 10: the scores of all rows lie within 1e-3 |q| of each other, far inside the
+    one-product error (~2e-3 |q||c|): the threshold kernel finds no room in the sample and flags every tile `precise`
+    (split-product scan); where even that scan's 2^-14 bound is too coarse the adaptive kernel redoes the tile.  Exact
+    either way."""
+    rng = np.random.default_rng(181)
+    n, nq, k, D = 100000, 512, 10, 64
+    c = np.full(D, 10.0 / np.sqrt(D), np.float32)
+    X = (c + 1e-3 * rng.standard_normal((n, D))).astype(np.float32)
+    Q = rng.standard_normal((nq, D)).astype(np.float32)
+    idx = make_index("negdotprod", "seq_search", X)
+    ids, ds, cnt = idx.knnQueryBatch(Q, k)
+    st = idx.stats()
+    assert st["last_path"] == 1 and st["fast_tiles"] >= 1 and st["fast_tiles_precise"] == st["fast_tiles"], st
+    sel = np.r_[0:16, nq - 16:nq]
+    opos, odist, _ = orc.seq_search("negdotprod", X, Q[sel], k + 22)
+    assert refio.recall_nmslib(ids[sel], opos, odist, k) >= 0.999
+    assert close_rel(ds[sel], odist[:, :k], rtol=1e-5, atol=1e-5)
+    idx.close()
+
+
+def test_f32_fast_path_low_dimensions():
+    """8-D rows (neighbours packed tightly in score): whichever scan the threshold kernel picks, no tile needs the
+    fallback and the answers are exact."""
+    n, nq, k = 200000, 512, 10
+    X, Q = refio.s_gauss(n, 8, 183), refio.s_gauss(nq, 8, 184)
+    idx = make_index("l2", "seq_search", X)
+    ids, ds, cnt = idx.knnQueryBatch(Q, k)
+    st = idx.stats()
+    assert st["last_path"] == 1 and st["fast_tiles_fallback"] == 0, st
+    sel = np.r_[0:16, nq - 16:nq]
+    opos, odist, _ = orc.seq_search("l2", X, Q[sel], k + 22)
+    assert refio.recall_nmslib(ids[sel], opos, odist, k) >= 0.999
+    assert close_rel(ds[sel], odist[:, :k], rtol=1e-5, atol=1e-6)
+    idx.close()
+
+
+def test_f32_fast_path_near_duplicates_stay_exact():
+    """Rows in tight clusters (1000 centres x 80 copies, noise 1e-3 of the norm): hundreds of rows per query sit inside
+    the one-product error of each other, and inside the cancellation error of the MFMA score -0.5|b|^2 + q.b itself.
+    l2: the answer is the reference's (it sums (a-b)^2: no cancellation) on every path -- lists that overflow fall back
+    to the adaptive kernel, whose re-rank proves its cut or hands the tile to the exact VALU kernel (BF_L2D).
+    cosinesimil: the reference formula 1 - q.b/(|q||b|) resolves 2^-24 of 1 while the members of a cluster differ by
+    ~1e-6: their order is rounding noise in the reference too -- the returned rows must be the query's own cluster and
+    the distances the oracle's within that resolution."""
+    rng = np.random.default_rng(191)
+    C = rng.standard_normal((1000, 64)).astype(np.float32)
+    X = (np.repeat(C, 80, axis=0) + 1e-3 * rng.standard_normal((80000, 64))).astype(np.float32)
+    cq = rng.integers(0, 1000, 600)
+    Q = (C[cq] + 1e-3 * rng.standard_normal((600, 64))).astype(np.float32)
+    sel = np.r_[0:12, 588:600]
+    for env in ({}, {"NMSLIB_GPU_F32_FAST": "0"}):
+        for k_, v in env.items():
+            os.environ[k_] = v
+        try:
+            idx = make_index("l2", "seq_search", X)
+            ids, ds, cnt = idx.knnQueryBatch(Q, 10)
+            assert idx.stats()["last_path"] == (0 if env else 1)
+            opos, odist, _ = orc.seq_search("l2", X, Q[sel], 10 + 22)
+            assert refio.recall_nmslib(ids[sel], opos, odist, 10) >= 0.999, env
+            assert close_rel(ds[sel], odist[:, :10], rtol=1e-5, atol=1e-6)
+            idx.close()
+        finally:
+            for k_ in env:
+                del os.environ[k_]
+    idx = make_index("cosinesimil", "seq_search", X)
+    ids, ds, cnt = idx.knnQueryBatch(Q, 10)
+    opos, odist, _ = orc.seq_search("cosinesimil", X, Q[sel], 10)
+    assert (ids[sel] // 80 == cq[sel][:, None]).all()
+    assert np.abs(ds[sel] - odist).max() <= 4 * 2.0 ** -24
     idx.close()
 
 
