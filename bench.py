@@ -397,8 +397,9 @@ def run_workload(a, name, cx):
     if os.path.exists(tr) and n == 1_000_000 and world == 1 and dim == WORKLOADS[name]["dim"] and not a.space:
         try:
             tj = json.load(open(tr))
-            roof["traffic"] = tj.get(roof["kernel"], tj.get(name))
-            roof["traffic_source"] = tj.get("source")
+            roof["traffic"] = tj.get(name)     # per workload: the same kernel moves other bytes on another shape
+            if roof["traffic"] is not None:
+                roof["traffic_source"] = tj.get("source")
         except Exception:
             pass
 
