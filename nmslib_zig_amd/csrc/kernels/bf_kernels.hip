@@ -1660,7 +1660,9 @@ __global__ __launch_bounds__(256) void bf_scan_f32_kernel(BfScanF32Args a) {
 // accumulators: the scores of block n are checked -- one group every other K-step, its dozen VALU instructions spread
 // under that step's MFMAs -- while block n+1 accumulates into the other set.
 // ---------------------------------------------------------------------------------------
-template <int MODE, int QG>
+// SAMPLE = the sample pass (every tile_stride-th tile; per-lane top-8 of the blocks' best scores instead of lists): the
+// SAME arithmetic as the scan, so a sampled row scores the same bits in both.
+template <int MODE, bool SAMPLE, int QG>
 __global__ __launch_bounds__(256) void bf_scan_bf16_kernel(BfScanF32Args a) {
     constexpr int NW = 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1679,14 +1681,17 @@ __global__ __launch_bounds__(256) void bf_scan_bf16_kernel(BfScanF32Args a) {
     constexpr int kSync = 4, kRing = 2 * kSync + 1, kAuxRing = 16, kStageBytes = BF_BN * 256;
     char* ring = smem;
     float* auxr = reinterpret_cast<float*>(ring + kRing * kStageBytes);  // [kAuxRing][BN]
+    const int tstr = SAMPLE ? a.tile_stride : 1;
     const int tiles_all = (a.n + BF_BN - 1) / BF_BN;
-    const int nstages = max(0, min(a.tps, tiles_all - split * a.tps));
-    const int r_begin = split * a.tps * BF_BN;
+    const int stiles_all = (tiles_all + tstr - 1) / tstr;
+    const int nstages = max(0, min(a.tps, stiles_all - split * a.tps));
+    const int r_begin = split * a.tps * tstr * BF_BN;
+    const int stage_rows = tstr * BF_BN;
 
     // one stage = 16 DMA pieces of 1 KiB (4 rows x 256 B): wave w issues pieces 4w .. 4w+3 and 16 of the 64 aux values
     auto issue_tile = [&](int stage) __attribute__((always_inline)) {
         const int slot = stage % kRing;
-        const int row0 = r_begin + stage * BF_BN;
+        const int row0 = r_begin + stage * stage_rows;
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
             const int pj = 4 * wave + jj;
@@ -1704,6 +1709,7 @@ __global__ __launch_bounds__(256) void bf_scan_bf16_kernel(BfScanF32Args a) {
     float thr[QG];
     int cnt[QG], ecnt[QG];
     uint32_t* lp[QG];
+    float t8[SAMPLE ? QG : 1][8];
 #pragma unroll
     for (int g = 0; g < QG; ++g) {
         const int qidx = (qt * NW + wave) * (32 * QG) + g * 32 + l31;
@@ -1712,8 +1718,15 @@ __global__ __launch_bounds__(256) void bf_scan_bf16_kernel(BfScanF32Args a) {
             asm volatile("global_load_dwordx4 %0, %1, off" : "=a"(qh[g][kc]) : "v"(a.q_hi + (size_t)qidx * 128 + 16 * kc + 8 * h) : "memory");
         cnt[g] = 0;
         ecnt[g] = 0;
-        thr[g] = a.thr[qidx];
-        lp[g] = a.list + (((size_t)qidx * a.nsplit + split) * 2 + h) * a.caph;
+        if constexpr (SAMPLE) {
+            thr[g] = -INFINITY;
+            lp[g] = nullptr;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) t8[g][i] = -INFINITY;
+        } else {
+            thr[g] = a.thr[qidx];
+            lp[g] = a.list + (((size_t)qidx * a.nsplit + split) * 2 + h) * a.caph;
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     for (int t = 0; t <= kSync && t < nstages; ++t) issue_tile(t);
@@ -1736,7 +1749,20 @@ __global__ __launch_bounds__(256) void bf_scan_bf16_kernel(BfScanF32Args a) {
     };
     // (see bf_scan_f32_kernel)
     auto finish_check = [&](float m, const f32x16& c, int g, const float* ax, int row0) __attribute__((always_inline)) {
-        if (__any(m >= thr[g])) {
+        if constexpr (SAMPLE) {
+            // only the block's best value enters the lane's top-8; pad rows of the dot / cosine modes score 0: the tile
+            // that holds them stays out of the estimate
+            if (__any(m > thr[g])) {
+                float v = (row0 + 32 <= a.n || MODE == SC_L2) ? m : -INFINITY;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float hi = fmaxf(t8[g][j], v);
+                    v = fminf(t8[g][j], v);
+                    t8[g][j] = hi;
+                }
+                thr[g] = t8[g][7];
+            }
+        } else if (__any(m >= thr[g])) {
             uint32_t km;
             if constexpr (MODE == SC_COS) {
                 f32x16 sc;
@@ -1795,7 +1821,7 @@ __global__ __launch_bounds__(256) void bf_scan_bf16_kernel(BfScanF32Args a) {
     for (int t = 0; t < nstages; ++t) {
         const uint32_t th_ = ring_a + (t % kRing) * kStageBytes;
         const float* axs = auxr + (t % kAuxRing) * BF_BN + 4 * h;
-        const int row0 = r_begin + t * BF_BN;
+        const int row0 = r_begin + t * stage_rows;
         const bool more = t + 1 < nstages;
 #pragma unroll
         for (int blk = 0; blk < 2; ++blk) {
@@ -1856,7 +1882,13 @@ __global__ __launch_bounds__(256) void bf_scan_bf16_kernel(BfScanF32Args a) {
 #pragma unroll
     for (int g = 0; g < QG; ++g) {
         const int qidx = (qt * NW + wave) * (32 * QG) + g * 32 + l31;
-        a.list_cnt[((size_t)qidx * a.nsplit + split) * 2 + h] = cnt[g];
+        if constexpr (SAMPLE) {
+            float* o = a.top8 + (((size_t)qidx * a.nsplit + split) * 2 + h) * 8;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o[i] = t8[g][i];
+        } else {
+            a.list_cnt[((size_t)qidx * a.nsplit + split) * 2 + h] = cnt[g];
+        }
     }
 }
 
@@ -1892,13 +1924,15 @@ __device__ __forceinline__ float one_product_error(const float* qs, int dim, int
 }
 
 // Thresholds of one query from the sample (the union of the lanes' top-8 lists, sorted); one workgroup per query.
-//   thr3 = the r-th best sample score: at least k' rows of the whole base reach it (see bf_f32_fast_plan), so the exact
-//          score S_k of the k-th neighbour is >= thr3.  The split-product scan lists the rows that reach it.
-//   thr1 = threshold for the one-product scan, whose scores are off by up to E1 (one_product_error): the first sample
-//          score at least 1.1 E1 below thr3 (unlisted rows then have an exact score < thr1 + E1 < S_k: the re-rank's
-//          proof holds).  If the sample has no such score among its best rcap -- the scores near the top are packed
-//          more tightly than the one-product error -- the query's tile is flagged `precise` and goes through the
-//          split-product scan.
+// The sample pass scores rows with ONE bf16 product: every sample score s^ is within E1 (one_product_error) of the
+// row's exact score s.  Let s^_r be the r-th best sample score: at least k' rows of the whole base score s^ >= s^_r
+// (see bf_f32_fast_plan), hence exact s >= s^_r - E1: the exact score S_k of the k-th neighbour is >= s^_r - E1.
+//   thr3 = s^_r - 1.02 E1 for the split-product scan (whose scores are exact to E3 << E1): it lists those k' rows.
+//   thr1 = threshold of the one-product scan (the sample's own arithmetic: a sampled row scores the same bits): the
+//          first sample score at least 2.1 E1 below s^_r.  Unlisted rows have s^ < thr1, so s < thr1 + E1
+//          <= s^_r - 1.1 E1 < S_k: the re-rank's proof holds.  If the sample has no such score among its best rcap --
+//          the scores near the top are packed more tightly than the one-product error -- the query's tile is flagged
+//          `precise` and goes through the split-product scan.
 // Only the `depth` best of each lane's eight enter the sort (a lane holds 1/nlists of the sample: more than four of the
 // best rcap in one lane is rare, and a dropped value only lowers a threshold).
 __global__ __launch_bounds__(256) void bf_f32_threshold_kernel(const float* top8, int nlists, int depth, int r, int rcap, int nq,
@@ -1929,12 +1963,12 @@ __global__ __launch_bounds__(256) void bf_f32_threshold_kernel(const float* top8
     __syncthreads();
     block_bitonic_u64_asc(keys, P, tid, blockDim.x);
     if (tid == 0) {
-        const float t3 = total >= r ? ord_f32(~(uint32_t)keys[r - 1]) : -INFINITY;
-        thr3[q] = t3;
+        const float t3 = total >= r ? ord_f32(~(uint32_t)keys[r - 1]) : -INFINITY;   // s^_r
+        thr3[q] = t3 - 1.02f * s_qn;
         float t1 = t3;
         bool ok = !force_precise;
         if (ok && t3 > -INFINITY) {
-            const float need = 1.1f * s_qn;
+            const float need = 2.1f * s_qn;
             const int jmax = rcap < total ? rcap : total;
             ok = false;
             for (int j = r; j <= jmax; ++j) {
@@ -2989,7 +3023,7 @@ BfF32Fast bf_f32_fast_plan(int n, int dim, int nq, int k, int space, bool cosine
     const int tq = 256 * f.qg;
     f.qpad = (nq + tq - 1) / tq * tq;
     f.nqt = f.qpad / tq;
-    f.stride = 16;  // (measured at C2: 8 -> 0.931, 16 -> 0.915, 32 -> 0.934 ms/step: a smaller sample is cheaper but lets more rows pass)
+    f.stride = 16;  // (measured at C2 with the one-product sample pass, ms/step: 4 -> 0.457, 8 -> 0.427, 16 -> 0.419)
     if (const char* e = getenv("NMSLIB_GPU_SAMPLE_STRIDE")) f.stride = atoi(e) > 0 ? atoi(e) : 16;
     // float spaces keep a slack of k' - k rows for the re-rank (the selection score is not the reference formula):
     // aim the threshold at k' = k + max(4, k/8)
@@ -3061,19 +3095,19 @@ static hipError_t launch_scan_f32_one(const BfScanF32Args& a, int grid, size_t l
     hipLaunchKernelGGL((bf_scan_f32_kernel<MODE, SAMPLE, QG>), dim3(grid), dim3(256), lds, s, a);
     return hipGetLastError();
 }
-template <int MODE, int QG>
+template <int MODE, bool SAMPLE, int QG>
 static hipError_t launch_scan_bf16_one(const BfScanF32Args& a, int grid, size_t lds, hipStream_t s) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bf_scan_bf16_kernel<MODE, QG>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bf_scan_bf16_kernel<MODE, SAMPLE, QG>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((bf_scan_bf16_kernel<MODE, QG>), dim3(grid), dim3(256), lds, s, a);
+    hipLaunchKernelGGL((bf_scan_bf16_kernel<MODE, SAMPLE, QG>), dim3(grid), dim3(256), lds, s, a);
     return hipGetLastError();
 }
-// terms: 3 = the split product (sample pass: always), 1 = one bf16 product
+// terms: 3 = the split product, 1 = one bf16 product (the sample pass: always, 256 queries per workgroup)
 template <int MODE>
 static hipError_t launch_scan_f32_mode(const BfScanF32Args& a, bool sample, int terms, int qg, int grid, size_t lds, hipStream_t s) {
-    if (sample) return launch_scan_f32_one<MODE, true, 2>(a, grid, lds, s);   // (the sample pass: 256 queries per workgroup)
-    if (terms == 1) return qg == 2 ? launch_scan_bf16_one<MODE, 4>(a, grid, lds, s) : launch_scan_bf16_one<MODE, 2>(a, grid, lds, s);
+    if (sample) return launch_scan_bf16_one<MODE, true, 2>(a, grid, lds, s);
+    if (terms == 1) return qg == 2 ? launch_scan_bf16_one<MODE, false, 4>(a, grid, lds, s) : launch_scan_bf16_one<MODE, false, 2>(a, grid, lds, s);
     if (qg == 2) return launch_scan_f32_one<MODE, false, 4>(a, grid, lds, s);
     return launch_scan_f32_one<MODE, false, 2>(a, grid, lds, s);
 }
@@ -3103,14 +3137,14 @@ hipError_t launch_bf_f32_fast(const BfF32Fast& f, int space, int n, int dim, int
     a.q_lo = static_cast<const __bf16*>(q_lo);
     a.n = n;
     a.nqt = f.nqt;
-    // 1. sample pass (split product: near-exact scores) + thresholds + the choice of the scan per query tile
+    // 1. sample pass (one product: the scores carry the error E1) + thresholds + the choice of the scan per query tile
     BfScanF32Args sa = a;
     sa.nqt = f.qpad / 256;
     sa.nsplit = f.s_nsplit;
     sa.tps = f.s_tps;
     sa.tile_stride = f.stride;
     sa.top8 = top8;
-    e = scan(sa, true, 3, 8 * sa.nqt * (f.s_nsplit / 8));
+    e = scan(sa, true, 1, 8 * sa.nqt * (f.s_nsplit / 8));
     if (e != hipSuccess) return e;
     e = hipMemsetAsync(tile_fail, 0, (size_t)f.nqt * 8, s);   // fallback flags + precise flags
     if (e != hipSuccess) return e;
