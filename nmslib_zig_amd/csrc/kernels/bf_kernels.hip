@@ -1284,22 +1284,32 @@ __global__ __launch_bounds__(256) void bf_rerank_u8_list_kernel(RerankListArgs a
     int qsq = 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) qsq = __builtin_amdgcn_udot4(qv[j], qv[j], qsq, false);
-    for (int j0 = wave * 8; j0 < total; j0 += 32) {
-        const int j = j0 + g8;
-        const uint32_t pos = (uint32_t)keys[j < total ? j : total - 1];
-        const i32x4 bv = *reinterpret_cast<const i32x4*>(a.base + (size_t)pos * 128 + sub * 16);
-        int bsq = 0, dot = 0;
+    // (four passes of 8 rows per wave requested together: 128 rows of the query in flight per workgroup round)
+    for (int j0 = wave * 32; j0 < total; j0 += 128) {
+        uint32_t pos[4];
+        i32x4 bv[4];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            bsq = __builtin_amdgcn_udot4(bv[t], bv[t], bsq, false);
-            dot = __builtin_amdgcn_udot4(bv[t], qv[t], dot, false);
+        for (int u = 0; u < 4; ++u) {
+            const int j = j0 + 8 * u + g8;
+            pos[u] = (uint32_t)keys[j < total ? j : total - 1];
+            bv[u] = *reinterpret_cast<const i32x4*>(a.base + (size_t)pos[u] * 128 + sub * 16);
         }
-        int d = qsq + bsq - 2 * dot;
-        d += __shfl_xor(d, 1, 64);
-        d += __shfl_xor(d, 2, 64);
-        d += __shfl_xor(d, 4, 64);
         __builtin_amdgcn_wave_barrier();
-        if (sub == 0 && j < total) keys[j] = ((u64)i32_ord(d) << 32) | pos;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            int bsq = 0, dot = 0;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                bsq = __builtin_amdgcn_udot4(bv[u][t], bv[u][t], bsq, false);
+                dot = __builtin_amdgcn_udot4(bv[u][t], qv[t], dot, false);
+            }
+            int d = qsq + bsq - 2 * dot;
+            d += __shfl_xor(d, 1, 64);
+            d += __shfl_xor(d, 2, 64);
+            d += __shfl_xor(d, 4, 64);
+            const int j = j0 + 8 * u + g8;
+            if (sub == 0 && j < total) keys[j] = ((u64)i32_ord(d) << 32) | pos[u];
+        }
     }
     for (int i = total + tid; i < P; i += blockDim.x) keys[i] = ~0ull;
     __syncthreads();
