@@ -1017,7 +1017,7 @@ __global__ __launch_bounds__(256, 2) void bf_scan_u8_kernel(BfScanArgs a) {
     const int split = (rest / a.nqt) * 8 + xcd;
     if (split >= a.nsplit) return;
 
-    constexpr int kRing = 6, kAuxRing = 8, kTileBytes = BF_BN * 128;
+    constexpr int kGroup = 4, kRing = 2 * kGroup, kAuxRing = 8, kTileBytes = BF_BN * 128;
     char* ring = smem;
     int* auxr = reinterpret_cast<int*>(ring + kRing * kTileBytes);
 
@@ -1072,11 +1072,10 @@ __global__ __launch_bounds__(256, 2) void bf_scan_u8_kernel(BfScanArgs a) {
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): retire the query loads before any DMA is counted
 
-    // Tiles are consumed in PAIRS: one counted wait + workgroup barrier per two tiles (128 rows).  Ring of six slots =
-    // the pair being read, the pair in flight behind it, the pair just requested.
-    for (int t = 0; t < 4 && t < nstages; ++t) issue_tile(t);
-    if (nstages > 2) asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");   // tiles 0, 1 landed; 2, 3 in flight
-    else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    // Tiles are consumed in GROUPS of four (256 rows): the waves meet once per group -- a wave that met a hit arrives late,
+    // the fewer meetings the less of that lateness everyone waits for -- with the group's tiles landed (requested one
+    // group earlier) and, behind the barrier, the previous group's slots free for the next requests.  Ring = 2 groups.
+    for (int t = 0; t < kGroup && t < nstages; ++t) issue_tile(t);
 
     const int sw = (l31 >> 1) & 7;
     // rows of one finished 32 x 64 block pair that reach the threshold: position appended to the lane's list
@@ -1107,19 +1106,26 @@ __global__ __launch_bounds__(256, 2) void bf_scan_u8_kernel(BfScanArgs a) {
                 ins(m1);
                 thr[g] = t8[g][7];
             }
-        } else if (__any(max(m0, m1) >= tg)) {
-            // one entry per 32-row block with a hit (see hit_mask_i32): the re-rank expands them
+        } else {
+            // one entry per 32-row block with a hit (see hit_mask_i32): the re-rank expands them.  Each block on its own
+            // trigger: at k = 100 a check meets a hit 4 times in 10, and a mask costs 32 VALU instructions
             const uint32_t blk = (uint32_t)(row0 - r_begin) >> 5;
-            const uint32_t k0 = hit_mask_i32(c0, tg), k1 = hit_mask_i32(c1, tg);
-            if (k0) {
-                if (ecnt[g] < a.caph) lp[g][ecnt[g]] = (blk << 16) | k0;
-                ecnt[g]++;
+            if (__any(m0 >= tg)) {
+                const uint32_t k0 = hit_mask_i32(c0, tg);
+                if (k0) {
+                    if (ecnt[g] < a.caph) lp[g][ecnt[g]] = (blk << 16) | k0;
+                    ecnt[g]++;
+                    cnt[g] += __builtin_popcount(k0);
+                }
             }
-            if (k1) {
-                if (ecnt[g] < a.caph) lp[g][ecnt[g]] = ((blk + 1) << 16) | k1;
-                ecnt[g]++;
+            if (__any(m1 >= tg)) {
+                const uint32_t k1 = hit_mask_i32(c1, tg);
+                if (k1) {
+                    if (ecnt[g] < a.caph) lp[g][ecnt[g]] = ((blk + 1) << 16) | k1;
+                    ecnt[g]++;
+                    cnt[g] += __builtin_popcount(k1);
+                }
             }
-            cnt[g] += __builtin_popcount(k0) + __builtin_popcount(k1);
         }
     };
 
@@ -1161,17 +1167,12 @@ __global__ __launch_bounds__(256, 2) void bf_scan_u8_kernel(BfScanArgs a) {
         }
         examine(p0, p1, QG - 1, row0);
     };
-    for (int t = 0; t < nstages; t += 2) {
-        // the slots of tiles t+4, t+5 held tiles t-2, t-1: every wave passed the last barrier after reading them
-        const int nnew = (t + 4 < nstages ? 1 : 0) + (t + 5 < nstages ? 1 : 0);
-        if (t + 4 < nstages) issue_tile(t + 4);
-        if (t + 5 < nstages) issue_tile(t + 5);
-        process_tile(t);
-        if (t + 1 < nstages) process_tile(t + 1);
-        // tiles t+2, t+3 must have landed; the tiles requested above (3 DMA instructions each) may stay in flight
-        if (nnew == 2) asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
-        else if (nnew == 1) asm volatile("s_waitcnt vmcnt(3)\n\ts_barrier" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    for (int t = 0; t < nstages; t += kGroup) {
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        for (int u = t + kGroup; u < t + 2 * kGroup && u < nstages; ++u) issue_tile(u);
+#pragma unroll
+        for (int u = 0; u < kGroup; ++u)
+            if (t + u < nstages) process_tile(t + u);
     }
 #pragma unroll
     for (int g = 0; g < QG; ++g) {
@@ -2908,7 +2909,7 @@ BfU8Fast bf_u8_fast_plan(int n, int nq, int k) {
     while (caph < 4.0 * mean_half + 8.0) caph <<= 1;
     f.caph = caph;
     f.p2max = host_next_pow2(2 * ns * caph);
-    f.lds_scan = 6 * BF_BN * 128 + 8 * BF_BN * 4 + 64;
+    f.lds_scan = 8 * BF_BN * 128 + 8 * BF_BN * 4 + 64;
     f.lds_rerank = (size_t)f.p2max * 8 + (2 * (size_t)ns + 1) * 4 + 16;
     // sample pass = the same streaming kernel over every stride-th tile, per-lane top-8 lists instead of thresholds
     // (always with 2 query groups per wave: twice the workgroups of the scan for the same row splits -- the sample
