@@ -1371,6 +1371,8 @@ struct BfScanF32Args {
 // fragment read from LDS feeds 3 * QG MFMAs.  (The first shape of this kernel -- 8 waves x 32 queries, two waves per
 // SIMD -- read 20 ds_read_b128 per wave and block: the LDS port was busy 1280 of the 1536 clocks the block's MFMAs
 // take, and two query groups per wave spilled at 256 registers.)
+// (SAMPLE = true, a sample pass with near-exact scores, is not instantiated any more: the sample pass runs
+//  bf_scan_bf16_kernel<MODE, true, 2> and the threshold kernel accounts for its error.)
 template <int MODE, bool SAMPLE, int QG>
 __global__ __launch_bounds__(256) void bf_scan_f32_kernel(BfScanF32Args a) {
     constexpr int NW = 4;
