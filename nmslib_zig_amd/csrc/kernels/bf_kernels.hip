@@ -2914,10 +2914,10 @@ BfU8Fast bf_u8_fast_plan(int n, int nq, int k) {
     f.lds_scan = 8 * BF_BN * 128 + 8 * BF_BN * 4 + 64;
     f.lds_rerank = (size_t)f.p2max * 8 + (2 * (size_t)ns + 1) * 4 + 16;
     // sample pass = the same streaming kernel over every stride-th tile, per-lane top-8 lists instead of thresholds
-    // (always with 2 query groups per wave: twice the workgroups of the scan for the same row splits -- the sample
-    //  has few stages per split, so it is split coarsely and parallelised over the queries instead)
+    // (in the scan's own shape -- 512 queries per workgroup at large batches: half the L2 -> LDS stream of the
+    //  256-query shape it first ran in)
     const int stiles = (tiles_all + f.stride - 1) / f.stride;
-    const int s_nqt = f.qpad / (BF_TQ * 2);
+    const int s_nqt = f.qpad / (BF_TQ * f.qg);   // (the scan's own shape: same workgroups per query tile)
     int nss = (256 + s_nqt - 1) / s_nqt;
     if (nss > stiles / 32) nss = stiles / 32;
     if (nss > 64) nss = 64;
@@ -2952,17 +2952,19 @@ hipError_t launch_bf_u8_fast(const BfU8Fast& f, int n, int nq, int k, const uint
     sa.auxh = auxh;
     sa.queries = queries_padded;
     sa.n = n;
-    const int s_nqt = f.qpad / (BF_TQ * 2);
+    const int s_nqt = f.qpad / (BF_TQ * f.qg);
     sa.nqt = s_nqt;
     sa.nsplit = f.s_nsplit;
     sa.tps = f.s_tps;
     sa.tile_stride = f.stride;
     sa.top8 = top8;
     {
-        hipError_t le = hipFuncSetAttribute(reinterpret_cast<const void*>(bf_scan_u8_kernel<2, true>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)f.lds_scan);
+        const void* fn = f.qg == 4 ? (const void*)bf_scan_u8_kernel<4, true> : (const void*)bf_scan_u8_kernel<2, true>;
+        hipError_t le = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)f.lds_scan);
         if (le != hipSuccess) return le;
-        hipLaunchKernelGGL((bf_scan_u8_kernel<2, true>), dim3(8 * s_nqt * (f.s_nsplit / 8)), dim3(256), f.lds_scan, s, sa);
+        const dim3 grid(8 * s_nqt * (f.s_nsplit / 8));
+        if (f.qg == 4) hipLaunchKernelGGL((bf_scan_u8_kernel<4, true>), grid, dim3(256), f.lds_scan, s, sa);
+        else hipLaunchKernelGGL((bf_scan_u8_kernel<2, true>), grid, dim3(256), f.lds_scan, s, sa);
         e = hipGetLastError();
     }
     if (e != hipSuccess) return e;
