@@ -494,6 +494,44 @@ def test_f32_fast_path_near_duplicates_stay_exact():
     idx.close()
 
 
+@pytest.mark.parametrize("stride", ["4", "8", "32"])
+def test_f32_fast_path_other_sample_strides(stride, monkeypatch):
+    """The thresholds come from a 1/stride sample scored with one bf16 product; whatever the stride, the proof in the
+    re-rank decides: exact answers, and on this data no tile needs the fallback."""
+    monkeypatch.setenv("NMSLIB_GPU_SAMPLE_STRIDE", stride)
+    n, nq = 150000, 1024
+    X, Q = refio.s_lowrank(n, 96, 201), refio.s_lowrank(nq, 96, 202)
+    for space, k in (("l2", 10), ("cosinesimil", 128)):
+        idx = make_index(space, "seq_search", X)
+        ids, ds, cnt = idx.knnQueryBatch(Q, k)
+        st = idx.stats()
+        assert st["last_path"] == 1 and st["fast_tiles_fallback"] == 0, (space, k, st)
+        sel = np.r_[0:8, nq - 8:nq]
+        opos, odist, _ = orc.seq_search(space, X, Q[sel], k + 22)
+        assert refio.recall_nmslib(ids[sel], opos, odist, k) >= 0.999, (space, k)
+        assert close_rel(ds[sel], odist[:, :k], rtol=1e-5, atol=1e-6)
+        idx.close()
+
+
+def test_f32_fast_path_zero_rows_and_zero_query():
+    """Zero rows (cosine: norm below the reference's epsilon -> similarity 0) and an all-zero query in a large batch:
+    every row ties for that query (lists overflow -> its tile falls back), the others are unaffected."""
+    n, nq, k = 70000, 512, 10
+    X, Q = refio.s_gauss(n, 64, 211), refio.s_gauss(nq, 64, 212)
+    X[100:140] = 0.0
+    Q[7] = 0.0
+    for space in ("l2", "cosinesimil", "negdotprod"):
+        idx = make_index(space, "seq_search", X)
+        ids, ds, cnt = idx.knnQueryBatch(Q, k)
+        assert (cnt == k).all()
+        sel = np.r_[0:16, nq - 8:nq]
+        opos, odist, _ = orc.seq_search(space, X, Q[sel], n if space != "l2" else k + 22)
+        keep = [i for i, q in enumerate(sel) if q != 7 or space == "l2"]
+        assert refio.recall_nmslib(ids[sel][keep], opos[keep], odist[keep], k) >= 0.999, space
+        assert close_rel(ds[sel], odist[:, :k], rtol=1e-5, atol=1e-6), space
+        idx.close()
+
+
 def test_fast_paths_with_batches_larger_than_one_slice():
     """40 000 queries (slices of 32 768 + 7 232) through the fast paths: results equal small batches through the
     adaptive path."""
