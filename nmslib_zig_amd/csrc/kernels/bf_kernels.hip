@@ -1093,7 +1093,7 @@ __global__ __launch_bounds__(256, 2) void bf_scan_u8_kernel(BfScanArgs a) {
             // only the best value of each 32-row block enters the lane's top-8: any threshold is admissible (the
             // re-rank verifies the outcome), a second value of the same block among a lane's eight best is rare, and
             // examining all 32 values whenever ANY of the 64 lanes has a hit would cost 16x the instructions
-            if (__any(max(m0, m1) > tg)) {
+            if (__builtin_expect(__any(max(m0, m1) > tg), 0)) {
                 auto ins = [&](int v) __attribute__((always_inline)) {
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
@@ -1110,7 +1110,7 @@ __global__ __launch_bounds__(256, 2) void bf_scan_u8_kernel(BfScanArgs a) {
             // one entry per 32-row block with a hit (see hit_mask_i32): the re-rank expands them.  Each block on its own
             // trigger: at k = 100 a check meets a hit 4 times in 10, and a mask costs 32 VALU instructions
             const uint32_t blk = (uint32_t)(row0 - r_begin) >> 5;
-            if (__any(m0 >= tg)) {
+            if (__builtin_expect(__any(m0 >= tg), 0)) {
                 const uint32_t k0 = hit_mask_i32(c0, tg);
                 if (k0) {
                     if (ecnt[g] < a.caph) lp[g][ecnt[g]] = (blk << 16) | k0;
@@ -1118,7 +1118,7 @@ __global__ __launch_bounds__(256, 2) void bf_scan_u8_kernel(BfScanArgs a) {
                     cnt[g] += __builtin_popcount(k0);
                 }
             }
-            if (__any(m1 >= tg)) {
+            if (__builtin_expect(__any(m1 >= tg), 0)) {
                 const uint32_t k1 = hit_mask_i32(c1, tg);
                 if (k1) {
                     if (ecnt[g] < a.caph) lp[g][ecnt[g]] = ((blk + 1) << 16) | k1;
@@ -1467,7 +1467,7 @@ __global__ __launch_bounds__(256) void bf_scan_f32_kernel(BfScanF32Args a) {
         if constexpr (SAMPLE) {
             // only the block's best value enters the lane's top-8 (see bf_scan_u8_kernel); pad rows of the dot / cosine
             // modes score 0: the tile that holds them keeps its real maximum out of the estimate only if that is negative
-            if (__any(m > thr[g])) {
+            if (__builtin_expect(__any(m > thr[g]), 0)) {
                 float v = (row0 + 32 <= a.n || MODE == SC_L2) ? m : -INFINITY;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
@@ -1477,7 +1477,7 @@ __global__ __launch_bounds__(256) void bf_scan_f32_kernel(BfScanF32Args a) {
                 }
                 thr[g] = t8[g][7];
             }
-        } else if (__any(m >= thr[g])) {
+        } else if (__builtin_expect(__any(m >= thr[g]), 0)) {   // (cold: the common path falls through)
             // one entry for the block if this lane has a hit (see hit_mask_f32): the re-rank expands them
             uint32_t km;
             if constexpr (MODE == SC_COS) {
@@ -1765,7 +1765,7 @@ __global__ __launch_bounds__(256) void bf_scan_bf16_kernel(BfScanF32Args a) {
         if constexpr (SAMPLE) {
             // only the block's best value enters the lane's top-8; pad rows of the dot / cosine modes score 0: the tile
             // that holds them stays out of the estimate
-            if (__any(m > thr[g])) {
+            if (__builtin_expect(__any(m > thr[g]), 0)) {
                 float v = (row0 + 32 <= a.n || MODE == SC_L2) ? m : -INFINITY;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
@@ -1775,7 +1775,7 @@ __global__ __launch_bounds__(256) void bf_scan_bf16_kernel(BfScanF32Args a) {
                 }
                 thr[g] = t8[g][7];
             }
-        } else if (__any(m >= thr[g])) {
+        } else if (__builtin_expect(__any(m >= thr[g]), 0)) {   // (cold: the common path falls through)
             uint32_t km;
             if constexpr (MODE == SC_COS) {
                 f32x16 sc;
@@ -1871,6 +1871,9 @@ __global__ __launch_bounds__(256) void bf_scan_bf16_kernel(BfScanF32Args a) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                     __builtin_amdgcn_sched_group_barrier(0x002, 12 / QG, 0);
                 }
+                // (pin the maximum in front of the branch: the compiler otherwise sinks its dozen instructions into the
+                //  `have_pv` block behind the MFMAs, where nothing hides them)
+                if (chk) asm volatile("" : "+v"(m));
                 __builtin_amdgcn_sched_barrier(0);
                 if (chk && have_pv) finish_check(m, acc[blk ^ 1][gc], gc, pv_ax, pv_row0);
                 __builtin_amdgcn_sched_barrier(0);
