@@ -1813,6 +1813,7 @@ __global__ __launch_bounds__(256) void bf_scan_bf16_kernel(BfScanF32Args a) {
     const float* pv_ax = auxr;
     int pv_row0 = 0;
     bool have_pv = false;
+    float m_pend = 0.f;       // maximum of the group whose compare + branch comes in the next K-step
     const uint32_t lds0 = (uint32_t)(uintptr_t)(lptr_t)smem;
     auto load_frag = [&](uint32_t rp, int kc) __attribute__((always_inline)) {
         asm volatile("ds_read_b128 %0, %1" : "=v"(fh[kc % 4]) : "v"(rp + foff[kc]) : "memory");
@@ -1859,23 +1860,36 @@ __global__ __launch_bounds__(256) void bf_scan_bf16_kernel(BfScanF32Args a) {
                     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fh[kc % 4]));
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                // group gc of the previous block is checked under this step's MFMAs
+                // The previous block's scores are checked one group per kEvery K-steps, in two halves: step gc * kEvery
+                // computes the group's maximum, its dozen VALU instructions spread under that step's MFMAs; the NEXT
+                // step compares and branches right behind its first MFMA, when the maximum is long there -- a compare +
+                // branch at the end of the step that computes it costs ~125 clocks (the wave issues in order: the branch
+                // waits for the VALU chain that waited for the step's last MFMA to issue; measured 252 vs 129 clocks
+                // per K-step).
                 constexpr int kEvery = 8 / QG;
                 const int gc = kc / kEvery;
-                const bool chk = (kc % kEvery) == kEvery - 1;
+                const bool chk = (kc % kEvery) == 0, br = (kc % kEvery) == 1;
                 float m = 0.f;
                 if (chk) m = block_max(acc[blk ^ 1][gc], pv_ax);   // (also before the first block: no branch between the MFMAs)
+                acc[blk][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[kc % 4], qh[0][kc], kc == 0 ? iv : acc[blk][0], 0, 0, 0);
+                if (br) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (have_pv) finish_check(m_pend, acc[blk ^ 1][gc], gc, pv_ax, pv_row0);
+                    __builtin_amdgcn_sched_barrier(0);
+                } else {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 12 / QG, 0);
+                }
 #pragma unroll
-                for (int g = 0; g < QG; ++g) {
+                for (int g = 1; g < QG; ++g) {
                     acc[blk][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[kc % 4], qh[g][kc], kc == 0 ? iv : acc[blk][g], 0, 0, 0);
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                     __builtin_amdgcn_sched_group_barrier(0x002, 12 / QG, 0);
                 }
-                // (pin the maximum in front of the branch: the compiler otherwise sinks its dozen instructions into the
-                //  `have_pv` block behind the MFMAs, where nothing hides them)
-                if (chk) asm volatile("" : "+v"(m));
-                __builtin_amdgcn_sched_barrier(0);
-                if (chk && have_pv) finish_check(m, acc[blk ^ 1][gc], gc, pv_ax, pv_row0);
+                if (chk) {   // (pinned here: the compiler would otherwise sink the maximum into the next step's branch)
+                    asm volatile("" : "+v"(m));
+                    m_pend = m;
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
             pv_ax = axs + blk * 32;
