@@ -1808,7 +1808,10 @@ __global__ __launch_bounds__(256) void bf_scan_bf16_kernel(BfScanF32Args a) {
 #pragma unroll
     for (int g = 0; g < QG; ++g) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc[0][g][i] = acc[1][g][i] = 0.f;
+        for (int i = 0; i < 16; ++i) {
+            acc[0][g][i] = 0.f;
+            acc[1][g][i] = -INFINITY;   // "the block before the first": reaches no threshold (no have-a-previous-block test
+        }                               //  in the loop: a uniform flag costs a VALU -> SALU round trip per branch)
     }
     const float* pv_ax = auxr;
     int pv_row0 = 0;
@@ -1874,7 +1877,7 @@ __global__ __launch_bounds__(256) void bf_scan_bf16_kernel(BfScanF32Args a) {
                 acc[blk][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[kc % 4], qh[0][kc], kc == 0 ? iv : acc[blk][0], 0, 0, 0);
                 if (br) {
                     __builtin_amdgcn_sched_barrier(0);
-                    if (have_pv) finish_check(m_pend, acc[blk ^ 1][gc], gc, pv_ax, pv_row0);
+                    finish_check(m_pend, acc[blk ^ 1][gc], gc, pv_ax, pv_row0);
                     __builtin_amdgcn_sched_barrier(0);
                 } else {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
