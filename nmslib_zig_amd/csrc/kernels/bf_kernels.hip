@@ -1761,11 +1761,15 @@ __global__ __launch_bounds__(256) void bf_scan_bf16_kernel(BfScanF32Args a) {
         return fmaxf(fmaxf(fmaxf(m[0], m[1]), m[2]), fmaxf(fmaxf(m[3], m[4]), score_of(c, 15, ax)));
     };
     // (see bf_scan_f32_kernel)
-    auto finish_check = [&](float m, const f32x16& c, int g, const float* ax, int row0) __attribute__((always_inline)) {
+    // does any lane's block maximum reach its threshold?  (a wave-uniform value in a scalar register)
+    auto trigger_of = [&](float m, int g) __attribute__((always_inline)) -> unsigned long long {
+        return SAMPLE ? __builtin_amdgcn_ballot_w64(m > thr[g]) : __builtin_amdgcn_ballot_w64(m >= thr[g]);
+    };
+    auto finish_check = [&](unsigned long long trig, float m, const f32x16& c, int g, const float* ax, int row0) __attribute__((always_inline)) {
         if constexpr (SAMPLE) {
             // only the block's best value enters the lane's top-8; pad rows of the dot / cosine modes score 0: the tile
             // that holds them stays out of the estimate
-            if (__builtin_expect(__any(m > thr[g]), 0)) {
+            if (__builtin_expect(trig != 0ull, 0)) {
                 float v = (row0 + 32 <= a.n || MODE == SC_L2) ? m : -INFINITY;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
@@ -1775,7 +1779,7 @@ __global__ __launch_bounds__(256) void bf_scan_bf16_kernel(BfScanF32Args a) {
                 }
                 thr[g] = t8[g][7];
             }
-        } else if (__builtin_expect(__any(m >= thr[g]), 0)) {   // (cold: the common path falls through)
+        } else if (__builtin_expect(trig != 0ull, 0)) {   // (cold: the common path falls through)
             uint32_t km;
             if constexpr (MODE == SC_COS) {
                 f32x16 sc;
@@ -1816,7 +1820,8 @@ __global__ __launch_bounds__(256) void bf_scan_bf16_kernel(BfScanF32Args a) {
     const float* pv_ax = auxr;
     int pv_row0 = 0;
     bool have_pv = false;
-    float m_pend = 0.f;       // maximum of the group whose compare + branch comes in the next K-step
+    float m_pend = 0.f;       // maximum (and trigger) of the group whose branch comes in the next K-step
+    unsigned long long trig_pend = 0ull;
     const uint32_t lds0 = (uint32_t)(uintptr_t)(lptr_t)smem;
     auto load_frag = [&](uint32_t rp, int kc) __attribute__((always_inline)) {
         asm volatile("ds_read_b128 %0, %1" : "=v"(fh[kc % 4]) : "v"(rp + foff[kc]) : "memory");
@@ -1877,7 +1882,7 @@ __global__ __launch_bounds__(256) void bf_scan_bf16_kernel(BfScanF32Args a) {
                 acc[blk][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[kc % 4], qh[0][kc], kc == 0 ? iv : acc[blk][0], 0, 0, 0);
                 if (br) {
                     __builtin_amdgcn_sched_barrier(0);
-                    finish_check(m_pend, acc[blk ^ 1][gc], gc, pv_ax, pv_row0);
+                    finish_check(trig_pend, m_pend, acc[blk ^ 1][gc], gc, pv_ax, pv_row0);
                     __builtin_amdgcn_sched_barrier(0);
                 } else {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -1889,9 +1894,15 @@ __global__ __launch_bounds__(256) void bf_scan_bf16_kernel(BfScanF32Args a) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                     __builtin_amdgcn_sched_group_barrier(0x002, 12 / QG, 0);
                 }
-                if (chk) {   // (pinned here: the compiler would otherwise sink the maximum into the next step's branch)
+                if (chk) {
+                    // the compare too belongs to this step: the branch of the next step then tests a scalar register that
+                    // has been there for a hundred clocks, not a VALU result.  (Pinned: the compiler would otherwise sink
+                    // the maximum and the compare into the next step's branch.)
                     asm volatile("" : "+v"(m));
+                    unsigned long long trig = trigger_of(m, gc);
+                    asm volatile("" : "+s"(trig));
                     m_pend = m;
+                    trig_pend = trig;
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -1910,7 +1921,10 @@ __global__ __launch_bounds__(256) void bf_scan_bf16_kernel(BfScanF32Args a) {
     }
     if (have_pv) {   // the last block (nstages > 0: it was block 1 of its stage)
 #pragma unroll
-        for (int g = 0; g < QG; ++g) finish_check(block_max(acc[1][g], pv_ax), acc[1][g], g, pv_ax, pv_row0);
+        for (int g = 0; g < QG; ++g) {
+            const float m = block_max(acc[1][g], pv_ax);
+            finish_check(trigger_of(m, g), m, acc[1][g], g, pv_ax, pv_row0);
+        }
     }
 #pragma unroll
     for (int g = 0; g < QG; ++g) {
