@@ -532,6 +532,30 @@ def test_f32_fast_path_zero_rows_and_zero_query():
         idx.close()
 
 
+@pytest.mark.parametrize("space", ["l2", "cosinesimil", "negdotprod", "angulardist"])
+def test_f32_fast_path_equals_adaptive_path_bit_for_bit(space, monkeypatch):
+    """The same batch through the fast path (bf16 scans + list re-rank) and through the adaptive f32-MFMA path
+    (NMSLIB_GPU_F32_FAST=0): the same rows in the same order with the same float distances -- both end in the reference
+    formula on the original rows, summed in the same order."""
+    n, nq, k = 200000, 1024, 10
+    X = np.vstack([refio.s_gauss(n // 2, 100, 221), refio.s_lowrank(n // 2, 100, 222)]).astype(np.float32)
+    Q = np.vstack([refio.s_gauss(nq // 2, 100, 223), refio.s_lowrank(nq // 2, 100, 224)]).astype(np.float32)
+    idx = make_index(space, "seq_search", X)
+    ids, ds, cnt = idx.knnQueryBatch(Q, k)
+    st = idx.stats()
+    assert st["last_path"] == 1 and st["fast_tiles_fallback"] == 0, st
+    monkeypatch.setenv("NMSLIB_GPU_F32_FAST", "0")
+    ids0, ds0, cnt0 = idx.knnQueryBatch(Q, k)
+    assert idx.stats()["last_path"] == 0
+    np.testing.assert_array_equal(cnt, cnt0)
+    same = (ids == ids0).all(axis=1)
+    # (rows whose distances agree to the last bit may swap between the two selections only if they tie exactly)
+    assert same.mean() >= 0.999, same.mean()
+    np.testing.assert_array_equal(ds[same], ds0[same])
+    np.testing.assert_array_equal(np.sort(ds, axis=1), np.sort(ds0, axis=1))
+    idx.close()
+
+
 def test_fast_paths_with_batches_larger_than_one_slice():
     """40 000 queries (slices of 32 768 + 7 232) through the fast paths: results equal small batches through the
     adaptive path."""
