@@ -1675,9 +1675,8 @@ __global__ __launch_bounds__(256) void bf_scan_f32_kernel(BfScanF32Args a) {
 // ---------------------------------------------------------------------------------------
 // SAMPLE = the sample pass (every tile_stride-th tile; per-lane top-8 of the blocks' best scores instead of lists): the
 // SAME arithmetic as the scan, so a sampled row scores the same bits in both.
-template <int MODE, bool SAMPLE, int QG>
-__global__ __launch_bounds__(256) void bf_scan_bf16_kernel(BfScanF32Args a) {
-    constexpr int NW = 4;
+template <int MODE, bool SAMPLE, int QG, int NW>
+__global__ __launch_bounds__(NW * 64) void bf_scan_bf16_kernel(BfScanF32Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = lane >> 5, l31 = lane & 31;
@@ -1706,16 +1705,16 @@ __global__ __launch_bounds__(256) void bf_scan_bf16_kernel(BfScanF32Args a) {
         const int slot = stage % kRing;
         const int row0 = r_begin + stage * stage_rows;
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-            const int pj = 4 * wave + jj;
+        for (int jj = 0; jj < 16 / NW; ++jj) {
+            const int pj = (16 / NW) * wave + jj;
             const int row = 4 * pj + (lane >> 4);
             const int c = (lane & 15) ^ (row & 15);
             const __bf16* src = a.base_hi + (size_t)(row0 + row) * 128 + c * 8;
             __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(ring + slot * kStageBytes + pj * 1024), 16, 0, 0);
         }
-        if (lane < 16)
-            __builtin_amdgcn_global_load_lds((gptr_t)(a.auxp + row0 + 16 * wave + lane),
-                                             (lptr_t)(auxr + (stage % kAuxRing) * BF_BN + 16 * wave), 4, 0, 0);
+        if (lane < 64 / NW)
+            __builtin_amdgcn_global_load_lds((gptr_t)(a.auxp + row0 + (64 / NW) * wave + lane),
+                                             (lptr_t)(auxr + (stage % kAuxRing) * BF_BN + (64 / NW) * wave), 4, 0, 0);
     };
 
     bf16x8 qh[QG][8];
@@ -1828,9 +1827,14 @@ __global__ __launch_bounds__(256) void bf_scan_bf16_kernel(BfScanF32Args a) {
     };
     auto load_init = [&](uint32_t ax) __attribute__((always_inline)) {
         if constexpr (MODE == SC_L2) {
-            asm volatile("ds_read_b128 v[240:243], %1\n\tds_read_b128 v[244:247], %1 offset:32\n\t"
-                         "ds_read_b128 v[248:251], %1 offset:64\n\tds_read_b128 v[252:255], %1 offset:96"
-                         : "={v[240:255]}"(iv) : "v"(ax) : "memory");
+            if constexpr (NW == 4)
+                asm volatile("ds_read_b128 v[240:243], %1\n\tds_read_b128 v[244:247], %1 offset:32\n\t"
+                             "ds_read_b128 v[248:251], %1 offset:64\n\tds_read_b128 v[252:255], %1 offset:96"
+                             : "={v[240:255]}"(iv) : "v"(ax) : "memory");
+            else   // (two waves per SIMD share the register file: stay low)
+                asm volatile("ds_read_b128 v[112:115], %1\n\tds_read_b128 v[116:119], %1 offset:32\n\t"
+                             "ds_read_b128 v[120:123], %1 offset:64\n\tds_read_b128 v[124:127], %1 offset:96"
+                             : "={v[112:127]}"(iv) : "v"(ax) : "memory");
         }
     };
     constexpr int kInitReads = MODE == SC_L2 ? 4 : 0;
@@ -1857,7 +1861,8 @@ __global__ __launch_bounds__(256) void bf_scan_bf16_kernel(BfScanF32Args a) {
                 // the next block's start values) stay in flight
                 if (kc + 2 < 8) {
                     load_frag(rp, kc + 2);
-                    if (kc == 0 && MODE == SC_L2) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(fh[0]), "+{v[240:255]}"(iv));
+                    if (kc == 0 && MODE == SC_L2 && NW == 4) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(fh[0]), "+{v[240:255]}"(iv));
+                    else if (kc == 0 && MODE == SC_L2) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(fh[0]), "+{v[112:127]}"(iv));
                     else asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(fh[kc % 4]));
                 } else if (has_next) {
                     if (kc == 6) load_init(nax);
@@ -3144,19 +3149,29 @@ static hipError_t launch_scan_f32_one(const BfScanF32Args& a, int grid, size_t l
     hipLaunchKernelGGL((bf_scan_f32_kernel<MODE, SAMPLE, QG>), dim3(grid), dim3(256), lds, s, a);
     return hipGetLastError();
 }
-template <int MODE, bool SAMPLE, int QG>
+template <int MODE, bool SAMPLE, int QG, int NW>
 static hipError_t launch_scan_bf16_one(const BfScanF32Args& a, int grid, size_t lds, hipStream_t s) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bf_scan_bf16_kernel<MODE, SAMPLE, QG>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bf_scan_bf16_kernel<MODE, SAMPLE, QG, NW>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((bf_scan_bf16_kernel<MODE, SAMPLE, QG>), dim3(grid), dim3(256), lds, s, a);
+    hipLaunchKernelGGL((bf_scan_bf16_kernel<MODE, SAMPLE, QG, NW>), dim3(grid), dim3(NW * 64), lds, s, a);
     return hipGetLastError();
 }
 // terms: 3 = the split product, 1 = one bf16 product (the sample pass: always, 256 queries per workgroup)
 template <int MODE>
 static hipError_t launch_scan_f32_mode(const BfScanF32Args& a, bool sample, int terms, int qg, int grid, size_t lds, hipStream_t s) {
-    if (sample) return launch_scan_bf16_one<MODE, true, 2>(a, grid, lds, s);
-    if (terms == 1) return qg == 2 ? launch_scan_bf16_one<MODE, false, 4>(a, grid, lds, s) : launch_scan_bf16_one<MODE, false, 2>(a, grid, lds, s);
+    // The one-product kernel runs with EIGHT waves per workgroup, two per SIMD, each serving half the query groups of the
+    // four-wave shape (same workgroup, same tile stream): its K-step is short (two MFMAs), and what one wave cannot hide at
+    // one wave per SIMD -- a branch, a VALU chain in front of it, the start-value copy -- the other wave's MFMAs cover.
+    // Measured at C2, same box: scan 0.2675 -> 0.2545 ms, sample pass too (step 0.400 -> 0.3925 ms); 512-query batches:
+    // scan 0.169 -> 0.155 ms.  NMSLIB_GPU_BF16_W8 (bits: 1 = 512-query tiles, 2 = 256-query tiles, 4 = sample pass) selects
+    // the shape for experiments; the split-product kernel needs the whole register file of a SIMD and stays at four waves.
+    static const int w8 = getenv("NMSLIB_GPU_BF16_W8") ? atoi(getenv("NMSLIB_GPU_BF16_W8")) : 7;
+    if (sample) return (w8 & 4) ? launch_scan_bf16_one<MODE, true, 1, 8>(a, grid, lds, s) : launch_scan_bf16_one<MODE, true, 2, 4>(a, grid, lds, s);
+    if (terms == 1) {
+        if (qg == 2) return (w8 & 1) ? launch_scan_bf16_one<MODE, false, 2, 8>(a, grid, lds, s) : launch_scan_bf16_one<MODE, false, 4, 4>(a, grid, lds, s);
+        return (w8 & 2) ? launch_scan_bf16_one<MODE, false, 1, 8>(a, grid, lds, s) : launch_scan_bf16_one<MODE, false, 2, 4>(a, grid, lds, s);
+    }
     if (qg == 2) return launch_scan_f32_one<MODE, false, 4>(a, grid, lds, s);
     return launch_scan_f32_one<MODE, false, 2>(a, grid, lds, s);
 }
