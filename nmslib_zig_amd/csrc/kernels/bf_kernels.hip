@@ -3166,7 +3166,8 @@ static hipError_t launch_scan_f32_mode(const BfScanF32Args& a, bool sample, int 
     // Measured at C2, same box: scan 0.2675 -> 0.2545 ms, sample pass too (step 0.400 -> 0.3925 ms); 512-query batches:
     // scan 0.169 -> 0.155 ms.  NMSLIB_GPU_BF16_W8 (bits: 1 = 512-query tiles, 2 = 256-query tiles, 4 = sample pass) selects
     // the shape for experiments; the split-product kernel needs the whole register file of a SIMD and stays at four waves.
-    static const int w8 = getenv("NMSLIB_GPU_BF16_W8") ? atoi(getenv("NMSLIB_GPU_BF16_W8")) : 7;
+    const char* w8e = getenv("NMSLIB_GPU_BF16_W8");
+    const int w8 = w8e ? atoi(w8e) : 7;
     if (sample) return (w8 & 4) ? launch_scan_bf16_one<MODE, true, 1, 8>(a, grid, lds, s) : launch_scan_bf16_one<MODE, true, 2, 4>(a, grid, lds, s);
     if (terms == 1) {
         if (qg == 2) return (w8 & 1) ? launch_scan_bf16_one<MODE, false, 2, 8>(a, grid, lds, s) : launch_scan_bf16_one<MODE, false, 4, 4>(a, grid, lds, s);

@@ -556,6 +556,28 @@ def test_f32_fast_path_equals_adaptive_path_bit_for_bit(space, monkeypatch):
     idx.close()
 
 
+def test_f32_fast_path_workgroup_shapes_agree(monkeypatch):
+    """The one-product kernels in their four-wave and eight-wave shapes (NMSLIB_GPU_BF16_W8 = 0 / 7) and both query-tile
+    sizes (NMSLIB_GPU_F32_QG = 1 / 2) list the same rows: identical answers, bit for bit."""
+    n, nq, k = 120000, 1024, 10
+    X, Q = refio.s_gauss(n, 128, 231), refio.s_gauss(nq, 128, 232)
+    idx = make_index("l2", "seq_search", X)
+    ref = None
+    for w8 in ("7", "0"):
+        for qg in ("2", "1"):
+            monkeypatch.setenv("NMSLIB_GPU_BF16_W8", w8)
+            monkeypatch.setenv("NMSLIB_GPU_F32_QG", qg)
+            ids, ds, cnt = idx.knnQueryBatch(Q, k)
+            st = idx.stats()
+            assert st["last_path"] == 1 and st["fast_tiles"] == (2 if qg == "2" else 4) and st["fast_tiles_fallback"] == 0, st
+            if ref is None:
+                ref = (ids, ds)
+            else:
+                np.testing.assert_array_equal(ids, ref[0])
+                np.testing.assert_array_equal(ds, ref[1])
+    idx.close()
+
+
 def test_fast_paths_with_batches_larger_than_one_slice():
     """40 000 queries (slices of 32 768 + 7 232) through the fast paths: results equal small batches through the
     adaptive path."""
