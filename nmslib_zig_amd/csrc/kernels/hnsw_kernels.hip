@@ -17,43 +17,16 @@
 #include <cstdio>
 #include <cstdlib>
 
+#include "hnsw_args.cuh"
 #include "hnsw_common.cuh"
 #include "kernels.hpp"
 
 namespace gfxknn {
 
-struct HnswArgs {
-    HnswDeviceGraph g;
-    const void* queries;
-    uint32_t* bitset;
-    size_t bitset_words;
-    int32_t* out_ids;
-    float* out_dists;
-    int32_t* out_cnt;
-    int32_t* out_ndc;
-    int32_t* out_hops;
-    int32_t* out_hops_up;
-    int32_t* status;
-    int nq, k, ef, cap;
-    int capa;  // cap rounded up to a multiple of 4 (keeps the LDS carve-up 16-byte aligned)
-    // construction mode (hnsw_build_kernels.hip): the query is a stored row, the best-first phase runs
-    // on `level`, and the start node is given (or found by descending from the entry point to level+1)
-    const int32_t* query_rows;   // [nq] row index of each query, or NULL (external queries)
-    const int32_t* start_nodes;  // [nq] start node (>= 0) or -1 = descend from the entry point; or NULL
-    int level;
-    int table_size, table_shift;
-    int prof;  // NMSLIB_HNSW_PROF: accumulate per-phase cycles into g_hnsw_prof (experiments only)
-    // visited-table overflow without the host: the LDS-table launch appends overflowed queries to fix_list; the
-    // bitset launch that follows (fix_mode) walks that list, each workgroup with its own bitset slot
-    int32_t* fix_list;
-    int32_t* fix_count;
-    int fix_mode;
-};
 
 // [0] descent, [1] pick + adjacency, [2] visited filter, [3] gather + distances, [4] accept + sort, [5] inserts, [6] waves
 __device__ unsigned long long g_hnsw_prof[8];
 
-constexpr uint32_t HT_EMPTY = 0xFFFFFFFFu;
 constexpr int SA_EMAX_MAX = 16;  // sorted array up to 64*16 = 1024 items
 
 // EMAX = sorted-array items per lane (cap <= 64*EMAX): 2 for ef <= 128, 4 for <= 256, 16 otherwise.
@@ -1022,7 +995,7 @@ HnswSearchPlan hnsw_make_plan(const HnswDeviceGraph& g, int nq, int k, int ef, b
     // and never let LDS push residency below 4 waves per CU (160 KB / 4).
     int want = 1 << ilog2((g.maxM0 > 0 ? g.maxM0 : 32) * p.cap * 2);
     if (want < 2048) want = 2048;
-    const size_t budget = 40 * 1024;
+    const size_t budget = 40 * 1024 - 64;
     while ((size_t)want * 4 + fixed > budget && want > 2048) want >>= 1;
     // ~18 distance evaluations per unit of ef on 1M-row graphs: beyond half load
     // the exact hash set is replaced by a per-query bitset in HBM
@@ -1048,6 +1021,20 @@ static hipError_t launch_space_w(const HnswArgs& a, const HnswSearchPlan& p, hip
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(kern, dim3(a.fix_mode ? a.fix_mode : a.nq), dim3(64), p.lds_bytes, s, a);
     } else {
+        if constexpr (!WIDE && EMAX <= 4 && SPACE != SP_L2SQR_SIFT) {
+            // small batches: one workgroup per query (control wave + gather waves).  NMSLIB_HNSW_MW=0 switches it
+            // off, =2 uses it for every batch size (experiments; the results are the same bits either way)
+            // (read per launch: the tests switch it inside one process)
+            const char* em = getenv("NMSLIB_HNSW_MW");
+            const char* eq = getenv("NMSLIB_HNSW_MW_MAXQ");
+            const int mode = em ? atoi(em) : 1;
+            const int max_nq = eq ? atoi(eq) : 2048;
+            if (mode && !a.query_rows && !a.start_nodes && a.level == 0 && (mode == 2 || a.nq <= max_nq)) {
+                const hipError_t me = launch_hnsw_search_mw(a, p.lds_bytes + 16, EMAX, s);
+                if (me != hipSuccess) return me;
+                return hipGetLastError();
+            }
+        }
         auto kern = hnsw_search_kernel<SPACE, false, EMAX, WIDE>;
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
@@ -1119,8 +1106,14 @@ hipError_t launch_hnsw_search_ex(const HnswDeviceGraph& g, const HnswSearchPlan&
         unsigned long long z[8] = {0};
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_hnsw_prof), z, sizeof(z));
         const double w = h[6] ? (double)h[6] : 1.0;
-        fprintf(stderr, "[hnsw_search] cycles/query: descent %.0f pick+adj %.0f visited %.0f gather %.0f accept %.0f insert %.0f\n",
-                h[0] / w, h[1] / w, h[2] / w, h[3] / w, h[4] / w, h[5] / w);
+        if (h[6])
+            fprintf(stderr, "[hnsw_search] cycles/query: descent %.0f pick+adj %.0f visited %.0f gather %.0f accept %.0f insert %.0f\n",
+                    h[0] / w, h[1] / w, h[2] / w, h[3] / w, h[4] / w, h[5] / w);
+        hnsw_mw_read_prof(h);
+        if (h[6])
+            fprintf(stderr, "[hnsw_search_mw] control-wave cycles/query: descent %.0f pick %.0f filter %.0f wait %.0f decide %.0f merge %.0f  (mispredicted %llu of %llu)\n",
+                    h[0] / (double)h[6], h[1] / (double)h[6], h[2] / (double)h[6], h[3] / (double)h[6], h[4] / (double)h[6],
+                    h[5] / (double)h[6], h[7], h[6]);
         return pe;
     }
     switch (g.space) {
