@@ -88,6 +88,9 @@ typedef struct {
     size_t fast_tiles;
     size_t fast_tiles_precise;
     size_t fast_tiles_fallback;
+    /* HNSW with the LDS visited table, last batch (reading it waits for the stream): queries whose table filled up and
+       that the HBM-bitset kernel answered again.  0 on every BASELINE configuration. */
+    size_t hnsw_redone;
 } nmslib_gpu_stats_t;
 nmslib_error_t nmslib_gpu_get_stats(nmslib_index_handle_t index, nmslib_gpu_stats_t* out);
 

@@ -52,7 +52,7 @@ class GpuStats(C.Structure):
     _fields_ = [("upload_seconds", C.c_double), ("build_seconds", C.c_double),
                 ("hbm_bytes", C.c_size_t), ("rows", C.c_size_t), ("dim", C.c_size_t), ("shards", C.c_size_t),
                 ("last_path", C.c_size_t), ("fast_tiles", C.c_size_t), ("fast_tiles_precise", C.c_size_t),
-                ("fast_tiles_fallback", C.c_size_t)]
+                ("fast_tiles_fallback", C.c_size_t), ("hnsw_redone", C.c_size_t)]
 
 
 def build_library(force=False):

@@ -695,9 +695,11 @@ nmslib_error_t nmslib_gpu_get_stats(nmslib_index_handle_t handle, nmslib_gpu_sta
     out->shards = e->shard_count() ? e->shard_count() : 1;
     out->last_path = (size_t)e->last_path;
     out->fast_tiles = out->fast_tiles_precise = out->fast_tiles_fallback = 0;
+    out->hnsw_redone = 0;
     return guarded(NMSLIB_ERROR_RUNTIME, "Failed to read statistics", [&] {
         std::lock_guard<std::mutex> lk(e->mu);
         e->fast_tile_counts(&out->fast_tiles, &out->fast_tiles_precise, &out->fast_tiles_fallback);
+        out->hnsw_redone = e->hnsw_redone();
     });
 }
 

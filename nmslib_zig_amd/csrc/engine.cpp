@@ -928,6 +928,7 @@ void Engine::knn_device(const void* d_queries, size_t nq, size_t elem_count, siz
     check_device();
     if (nq == 0) return;
     if (k == 0) throw EngineError(Err::InvalidArgument, "k must be positive");
+    last_stream_ = stream;
     if (!shards_.empty()) {
         if (size() > 0 && elem_count != dim_)
             throw EngineError(Err::QueryExecutionFailed, "query dimension does not match the index");
@@ -966,7 +967,7 @@ void Engine::fast_tile_counts(size_t* tiles, size_t* precise, size_t* fallback) 
     if ((last_path != 1 && last_path != 3) || !fast_flags_ || fast_nqt_ <= 0) return;
     std::vector<int> h((size_t)fast_nqt_ * 2, 0);
     hip_check(hipSetDevice(device_), "hipSetDevice");
-    hip_check(hipStreamSynchronize(stream_), "stats");
+    hip_check(hipStreamSynchronize(last_stream_ ? last_stream_ : stream_), "stats");
     hip_check(hipMemcpy(h.data(), fast_flags_, (size_t)fast_nqt_ * (fast_has_precise_ ? 2 : 1) * sizeof(int), hipMemcpyDeviceToHost),
               "stats flags");
     *tiles = (size_t)fast_nqt_;
@@ -974,6 +975,16 @@ void Engine::fast_tile_counts(size_t* tiles, size_t* precise, size_t* fallback) 
         *fallback += h[i] != 0;
         if (fast_has_precise_) *precise += h[(size_t)fast_nqt_ + i] != 0;
     }
+}
+
+size_t Engine::hnsw_redone() {
+    if (!shards_.empty()) return shards_[0]->hnsw_redone();
+    if (last_path != 4 || !hnsw_fix_valid_) return 0;
+    int32_t v = 0;
+    hip_check(hipSetDevice(device_), "hipSetDevice");
+    hip_check(hipStreamSynchronize(last_stream_ ? last_stream_ : stream_), "stats");
+    hip_check(hipMemcpy(&v, ws_fix_.ptr(), 4, hipMemcpyDeviceToHost), "stats redo count");
+    return (size_t)v;
 }
 
 void Engine::knn_brute(const void* d_queries, size_t nq, size_t k, int32_t* d_ids, float* d_dists, int32_t* d_cnt,
@@ -1132,6 +1143,7 @@ void Engine::knn_hnsw(const void* d_queries, size_t nq, size_t k, int32_t* d_ids
                       hipStream_t stream) {
     const int ef = ef_;
     last_path = 4;
+    hnsw_fix_valid_ = false;
     // Hnsw::Search, hnsw.cc:724: algoType=old, or hybrid with ef >= 1000, runs SearchOld
     if (algo_ == "old" || (algo_ == "hybrid" && ef >= 1000)) {
         knn_hnsw_old(d_queries, nq, k, d_ids, d_dists, d_cnt, stream);
@@ -1172,6 +1184,7 @@ void Engine::knn_hnsw(const void* d_queries, size_t nq, size_t k, int32_t* d_ids
     int32_t* fix_count = ws_fix_.as<int32_t>();
     int32_t* fix_list = fix_count + 16;
     hip_check(hipMemsetAsync(fix_count, 0, 4, stream), "clear overflow count");
+    hnsw_fix_valid_ = true;
     prof_begin(stream);
     hip_check(launch_hnsw_search_fix(dg_, p, d_queries, nullptr, 0, fix_list, fix_count, d_ids, d_dists, cnt, ndc, hops,
                                      hops_up, status, stream),

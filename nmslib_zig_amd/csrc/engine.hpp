@@ -173,6 +173,10 @@ class Engine {
     int fast_nqt_ = 0;
     bool fast_has_precise_ = false;
     void fast_tile_counts(size_t* tiles, size_t* precise, size_t* fallback);
+    // HNSW (LDS visited table): queries of the last batch that were re-run by the bitset kernel (waits for the batch)
+    size_t hnsw_redone();
+    hipStream_t last_stream_ = nullptr;  // stream of the most recent batch (the statistics wait for THAT one)
+    bool hnsw_fix_valid_ = false;
     size_t hbm_bytes() const;
 
     std::mutex mu;  // serialises finalize + queries on one index

@@ -118,53 +118,73 @@ __device__ __forceinline__ void mw_gather_loop(const HnswArgs& a, const float* q
     }
 }
 
-template <int SPACE, int SA_EMAX>
-__device__ __forceinline__ void mw_control(const HnswArgs& a, const int q, float* keys, int* idu, float* qv, int* nbr,
-                                           float* nd, float* sk, int* si, int* ctl, uint32_t* table, const int lane) {
+// wave_shr:1 -- lane i takes lane i-1 of the whole wave (lane 0 keeps its own value)
+template <typename T>
+__device__ __forceinline__ T dpp_wave_shr1(T v) {
+    const int x = __builtin_bit_cast(int, v);
+    return __builtin_bit_cast(T, __builtin_amdgcn_update_dpp(x, x, 0x138, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float readlane_f(float v, int l) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+// lane mask of a per-lane condition, straight from the compare (no 0/1 round trip through a VGPR)
+#define BALLOT(x) ((u64)__builtin_amdgcn_ballot_w64(x))
+__device__ __forceinline__ int mbcnt64(u64 m) {  // set bits of m below this lane
+    return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+
+// The control wave.  The sorted array (SortArrBI, include/sort_arr_bi.h) lives in REGISTERS: item i = lane i%64 of
+// register i/64 (key; id | used<<31; free slots: +inf, -1).  A lone wave pays ~10 clocks per instruction in code like
+// this (scalar/vector ping-pong, short branches), so the loop is written for instruction count: wave-uniform control
+// flow only (no per-lane branches: the compiler turns those into exec-mask state machines), the first unused item is
+// the lowest set bit of ballot(id >= 0), picking it is a readlane, one accepted item is inserted with two ballots and
+// one wave_shr:1 per register (SortArrBI::push_or_replace_non_empty_exp, :159-199), several at once by counting
+// (hnsw_search_body's merge) through an LDS scatter.
+template <int SPACE, int E, bool PROF>
+__device__ __forceinline__ void mw_control(const HnswArgs& a, const int q, float* keys, int* idu, int* nbr, float* nd,
+                                           int* ctl, uint32_t* table, const int lane) {
     const HnswDeviceGraph& g = a.g;
     int ndc = 0, hops = 0, hops_up = 0, nvisited = 0;
-    bool overflow = false, inflight = false;
+    bool inflight = false;
+    const uint32_t tmask = (uint32_t)a.table_size - 1u;
+    const int tfull = a.table_size - (a.table_size >> 3);
 
-    auto visit = [&](uint32_t id) -> bool {
-        uint32_t hsh = (id * 2654435761u) >> a.table_shift;
-        const uint32_t mask = (uint32_t)a.table_size - 1u;
-        for (int probe = 0; probe < a.table_size; ++probe) {
-            const uint32_t old = atomicCAS(&table[hsh], HT_EMPTY, id);
-            if (old == HT_EMPTY) return true;
-            if (old == id) return false;
-            hsh = (hsh + 1) & mask;
+    // visited filter of an adjacency list v (lane L: neighbour L; lane 63: the count): test-and-set in the LDS hash
+    // (exact), the unvisited neighbours go to nbr[0..m), the rest of nbr[] is padded with the last of them, ctl[0] = m.
+    // Wave-uniform probe loop: lanes that are done keep issuing a compare-and-swap that cannot match.
+    auto filter = [&](const int v) __attribute__((always_inline)) -> int {
+        const int cntn = __builtin_amdgcn_readlane(v, 63);
+        // (the loop state is kept as lane masks in scalar registers: per-lane booleans carried around a loop are
+        //  rebuilt by the compiler through a 0/1 VGPR every iteration)
+        u64 pm = BALLOT(lane < cntn), nm = 0;
+        uint32_t h = ((uint32_t)v * 2654435761u) >> a.table_shift;
+        while (pm) {
+            const bool pend = __builtin_amdgcn_inverse_ballot_w64(pm);
+            const uint32_t old = atomicCAS(&table[h], pend ? HT_EMPTY : 0xFFFFFFFEu, (uint32_t)v);
+            const u64 got = BALLOT(old == HT_EMPTY) & pm;
+            nm |= got;
+            pm &= ~got & BALLOT(old != (uint32_t)v);
+            h = (h + 1) & tmask;
         }
-        return false;
+        const bool isn = __builtin_amdgcn_inverse_ballot_w64(nm);
+        const int m = __popcll(nm);
+        if (m > 0) {
+            const int lastid = __builtin_amdgcn_readlane(v, 63 - __clzll((long long)nm));
+            const int pos = mbcnt64(nm);
+            nbr[isn ? pos : m + lane - pos] = isn ? v : lastid;  // every lane writes exactly one of the 64 slots
+            ctl[0] = m;
+        }
+        nvisited += m;
+        return m;
     };
-    auto publish = [&](int m) __attribute__((always_inline)) {
-        if (lane == 0) ctl[0] = m;
-        mw_barrier();  // A
-    };
-    // adjacency of node c, shifted by one word: lane L holds neighbour L, the last lanes hold the count (word 0)
-    auto load_adj0 = [&](int c) -> int {
+    auto load_adj0 = [&](int c) __attribute__((always_inline)) -> int {
         const int w = lane + 1 <= g.maxM0 ? lane + 1 : 0;
         return g.links0[(size_t)c * (g.maxM0 + 1) + w];
     };
-    // visited filter of an adjacency list: the unvisited neighbours go to nbr[0..m), padded with the last one
-    auto filter = [&](int v) -> int {
-        const int cntn = __builtin_amdgcn_readlane(v, 63);
-        bool isn = false;
-        if (lane < cntn) isn = visit((uint32_t)v);
-        const u64 nmask = __ballot(isn);
-        const int m = __popcll(nmask);
-        if (m > 0) {
-            const int lastid = __builtin_amdgcn_readlane(v, 63 - __clzll((long long)nmask));
-            if (isn) nbr[__popcll(nmask & ((1ull << lane) - 1ull))] = v;
-            if (lane >= m) nbr[lane] = lastid;
-        }
-        nvisited += m;
-        if (nvisited > (a.table_size - (a.table_size >> 3))) overflow = true;
-        return m;
-    };
     long long pc[6] = {0, 0, 0, 0, 0, 0};
-    long long pt = a.prof ? (long long)__builtin_readcyclecounter() : 0;
+    long long pt = PROF ? (long long)__builtin_readcyclecounter() : 0;
     auto lap = [&](int ph) __attribute__((always_inline)) {
-        if (a.prof) {
+        if constexpr (PROF) {
             const long long now = (long long)__builtin_readcyclecounter();
             pc[ph] += now - pt;
             pt = now;
@@ -174,7 +194,8 @@ __device__ __forceinline__ void mw_control(const HnswArgs& a, const int q, float
     // ---- entry point + greedy descent (hnsw_distfunc_opt.cc:168-198) ----
     int cur = g.enterpoint;
     nbr[lane] = cur;
-    publish(1);
+    ctl[0] = 1;
+    mw_barrier();  // A
     mw_barrier();  // B
     float curdist = nd[0];
     ndc += 1;
@@ -189,14 +210,15 @@ __device__ __forceinline__ void mw_control(const HnswArgs& a, const int q, float
             if (cntl > 0) {
                 const int lastid = __builtin_amdgcn_readlane(v, cntl - 1);
                 nbr[lane] = lane < cntl ? v : lastid;
-                publish(cntl);
+                ctl[0] = cntl;
+                mw_barrier();  // A
                 mw_barrier();  // B
                 ndc += cntl;
                 // sequential "if (d < curdist)" scan == first index attaining the minimum
                 const float dl = lane < cntl ? nd[lane] : INFINITY;
                 const float dmin = wave_min_f32(dl);
                 if (dmin < curdist) {
-                    const u64 mm = __ballot(lane < cntl && dl == dmin);
+                    const u64 mm = BALLOT((lane < cntl) & (dl == dmin));
                     curdist = dmin;
                     cur = __builtin_amdgcn_readlane(v, __ffsll((long long)mm) - 1);
                     changed = true;
@@ -206,290 +228,293 @@ __device__ __forceinline__ void mw_control(const HnswArgs& a, const int q, float
     }
 
     // ---- level 0 (hnsw_distfunc_opt.cc:200-274) ----
+    float kreg[E];
+    int ireg[E], posv[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        posv[e] = lane + 64 * e;
+        kreg[e] = (e == 0 && lane == 0) ? curdist : INFINITY;
+        ireg[e] = (e == 0 && lane == 0) ? cur : -1;
+    }
     int n = 1;
-    if (lane == 0) {
-        keys[0] = curdist;
-        idu[0] = cur;
-        (void)visit((uint32_t)cur);
+    {   // the start node is visited (one lane inserts it; nothing else is in the table yet)
+        const uint32_t h = ((uint32_t)cur * 2654435761u) >> a.table_shift;
+        table[h] = (uint32_t)cur;
     }
     nvisited = 1;
-    __builtin_amdgcn_wave_barrier();
 
-    auto first_unused = [&](int from) -> int {
-        int fu = n;
-        for (int base = from; base < n && fu == n; base += 64) {
-            const int i = base + lane;
-            const u64 mk = __ballot(i < n && idu[i] >= 0);
-            if (mk) fu = base + (__ffsll((long long)mk) - 1);
+    auto key_at = [&](int i) __attribute__((always_inline)) -> float {  // i uniform
+        float r = readlane_f(kreg[0], i & 63);
+#pragma unroll
+        for (int e = 1; e < E; ++e) {
+            const float x = readlane_f(kreg[e], i & 63);
+            r = (i >> 6) == e ? x : r;
+        }
+        return r;
+    };
+    auto id_at = [&](int i) __attribute__((always_inline)) -> int {
+        int r = __builtin_amdgcn_readlane(ireg[0], i & 63);
+#pragma unroll
+        for (int e = 1; e < E; ++e) {
+            const int x = __builtin_amdgcn_readlane(ireg[e], i & 63);
+            r = (i >> 6) == e ? x : r;
+        }
+        return r;
+    };
+    // first unused item: lowest set bit of ballot(id >= 0) (64*E when there is none)
+    auto first_unused = [&]() __attribute__((always_inline)) -> int {
+        int fu = 64 * E;
+#pragma unroll
+        for (int e = E - 1; e >= 0; --e) {
+            const u64 U = BALLOT(ireg[e] >= 0);
+            fu = U ? 64 * e + (int)__builtin_ctzll(U) : fu;
         }
         return fu;
     };
+    // SortArrBI::push_or_replace_non_empty_exp (sort_arr_bi.h:159-199) for one item
+    auto insert = [&](const float key, const int id) __attribute__((always_inline)) {
+        const float lastk = key_at(n - 1);
+        int p, newn;
+        if (lastk <= key) {
+            if (n >= a.cap) return;
+            p = n;
+            newn = n + 1;
+        } else {
+            // insertion index.  Without a key equal to the new one in the array, the reference's exponential probe +
+            // lower_bound (:172-186) is simply the number of smaller keys; with equal keys present (rare) the probe
+            // is replayed so that the item lands inside the run exactly where the reference puts it.
+            int less = 0, leq = 0;
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                less += __popcll(BALLOT(kreg[e] < key));
+                leq += __popcll(BALLOT(kreg[e] <= key));
+            }
+            p = less;
+            if (leq != less) {
+                int curr = n - 1, prev = curr, dstep = 1;
+                while (curr > 0 && key_at(curr) > key) {
+                    prev = curr;
+                    curr -= dstep;
+                    dstep *= 2;
+                    if (dstep > curr) dstep = curr;
+                }
+                p = curr;
+                for (int i = curr; i < prev && key_at(i) < key; ++i) p = i + 1;
+            }
+            newn = n < a.cap ? n + 1 : a.cap;
+        }
+        float shk[E];
+        int shi[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            shk[e] = dpp_wave_shr1(kreg[e]);
+            shi[e] = dpp_wave_shr1(ireg[e]);
+        }
+#pragma unroll
+        for (int e = 1; e < E; ++e) {  // lane 0 of a register continues lane 63 of the one before
+            const float ck = readlane_f(kreg[e - 1], 63);
+            const int ci = __builtin_amdgcn_readlane(ireg[e - 1], 63);
+            shk[e] = lane == 0 ? ck : shk[e];
+            shi[e] = lane == 0 ? ci : shi[e];
+        }
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const bool mv = posv[e] > p && posv[e] < newn;
+            const bool at = posv[e] == p;
+            kreg[e] = at ? key : (mv ? shk[e] : kreg[e]);
+            ireg[e] = at ? id : (mv ? shi[e] : ireg[e]);
+        }
+        n = newn;
+    };
+    // the accepted items of one expansion (lanes with acc: dj, idj) into the array, in ascending order of
+    // (distance, list position) exactly as hnsw_distfunc_opt.cc:251-266 inserts them one after the other
+    auto merge = [&](const float dj, const int idj, const bool acc, const u64 amask, const int m2) __attribute__((always_inline)) {
+        if (m2 == 1) {
+            const int j = (int)__builtin_ctzll(amask);
+            insert(readlane_f(dj, j), __builtin_amdgcn_readlane(idj, j));
+            return;
+        }
+        // several: rank of every accepted item among them, number of accepted keys below every old item, number of
+        // old keys below every accepted item -- then every item knows its place in the merged array (cut at the
+        // capacity).  Two equal keys anywhere (rare): one insertion at a time instead, in rank order.
+        int rank = 0, less = 0;
+        int cnt[E];
+        u64 tie = 0;
+#pragma unroll
+        for (int e = 0; e < E; ++e) cnt[e] = 0;
+        for (u64 mm = amask; mm; mm &= mm - 1) {
+            const int j = (int)__builtin_ctzll(mm);
+            const float kt = readlane_f(dj, j);
+            rank += ((kt < dj) | ((kt == dj) & (j < lane))) ? 1 : 0;
+            int lt = 0;
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                lt += __popcll(BALLOT(kreg[e] < kt));
+                cnt[e] += kt < kreg[e] ? 1 : 0;
+                tie |= BALLOT(kt == kreg[e]);
+            }
+            tie |= BALLOT(acc & (kt == dj) & (j != lane));
+            less = lane == j ? lt : less;
+        }
+        if (tie == 0) {
+            const int newn = n + m2 < a.cap ? n + m2 : a.cap;
+            const int first = __builtin_amdgcn_readlane(less, (int)__builtin_ctzll(BALLOT(acc & (rank == 0))));
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const int np = posv[e] + cnt[e];
+                if (cnt[e] > 0 && np < newn) {  // (free slots have key +inf: cnt = m2, np >= n + m2 >= newn)
+                    keys[np] = kreg[e];
+                    idu[np] = ireg[e];
+                }
+            }
+            {
+                const int np = less + rank;
+                if (acc && np < newn) {
+                    keys[np] = dj;
+                    idu[np] = idj;
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const bool ch = posv[e] >= first && posv[e] < newn;
+                const float k2 = keys[ch ? posv[e] : 0];
+                const int i2 = idu[ch ? posv[e] : 0];
+                kreg[e] = ch ? k2 : kreg[e];
+                ireg[e] = ch ? i2 : ireg[e];
+            }
+            n = newn;
+        } else {
+            for (int t = 0; t < m2; ++t) {
+                const int j = (int)__builtin_ctzll(BALLOT(acc & (rank == t)));
+                insert(readlane_f(dj, j), __builtin_amdgcn_readlane(idj, j));
+            }
+        }
+    };
 
-    int cursor = 0;
     // pre_*: the array's first unused item behind the node being expanded, with its adjacency requested early
     int pre_node = -1, pre_v = 0;
     float pre_key = INFINITY;
     bool pre_ok = false;
-    // pipe_*: the node of the NEXT expansion, named before the merge; its rows are already with the gather waves
-    int pipe_node = -1, pipe_m = 0;
-    bool bad = false;
+    // P: the node of the NEXT expansion, named before the merge (-1: not named; the sequential pick decides)
+    int P = -1, Pv = 0;
+    // accepted items of the expansion whose merge is pending
+    float dj = INFINITY;
+    int idj = -1, m2 = 0;
+    bool acc = false;
+    u64 amask = 0;
+    int status = 0;  // 1: the visited table is nearly full, 2: the early choice was not the sequential one (cannot happen)
     lap(0);
     while (true) {
-        const int lim = n < a.ef ? n : a.ef;
-        const int fu = first_unused(cursor);
-        if (fu >= lim) break;
-        const int c = idu[fu] & 0x7FFFFFFF;
-        if (lane == 0) idu[fu] |= (int)0x80000000;
-        cursor = fu + 1;
-        hops++;
-        const float topKey = keys[n - 1];
-        const int size0 = n;
-        int m;
-        if (c == pipe_node) {
-            m = pipe_m;
-            pipe_node = -1;
-            lap(1);
-        } else {
-            if (pipe_node >= 0) {  // cannot happen: the pipelined choice is the sequential one
-                bad = true;
-                break;
-            }
-            lap(1);
-            const int v = (c == pre_node) ? pre_v : load_adj0(c);
-            m = filter(v);
-            if (overflow) break;
-            if (m > 0) {
-                publish(m);
-                inflight = true;
-            }
+        if (P < 0) {
+            // nothing named: finish the merge, then the sequential pick (:204-215)
+            if (m2 > 0) merge(dj, idj, acc, amask, m2);
+            m2 = 0;
+            const int fu0 = first_unused();
+            if (fu0 >= (n < a.ef ? n : a.ef)) break;
+            P = id_at(fu0);
+            Pv = (P == pre_node) ? pre_v : load_adj0(P);
             lap(2);
         }
-        {   // adjacency of the likely next expansion, one expansion early (a random HBM read: ~1 us)
-            const int fu2 = first_unused(cursor);
-            if (fu2 < lim) {
-                const int node = idu[fu2] & 0x7FFFFFFF;
-                if (node != pre_node) {
-                    pre_node = node;
-                    pre_v = load_adj0(node);
-                }
-                pre_key = keys[fu2];
-                pre_ok = true;
-            } else {
-                pre_node = -1;
-                pre_key = INFINITY;
-                pre_ok = false;
-            }
+        // ---- visited filter of P; its rows go to the gather waves ----
+        const int m = filter(Pv);
+        if (nvisited > tfull) {
+            status = 1;
+            break;
         }
+        if (m > 0) {
+            mw_barrier();  // A
+            inflight = true;
+        }
+        lap(4);
+        // ---- while they work: the merge of the previous expansion, then the pick of this one ----
+        if (m2 > 0) merge(dj, idj, acc, amask, m2);
+        m2 = 0;
+        lap(5);
+        const int lim = n < a.ef ? n : a.ef;
+        const int fu = first_unused();
+        const int c = fu < lim ? id_at(fu) : -2;
+        if (c != P) {
+            status = 2;
+            break;
+        }
+#pragma unroll
+        for (int e = 0; e < E; ++e) ireg[e] = posv[e] == fu ? (c | (int)0x80000000) : ireg[e];
+        hops++;
+        const float topKey = key_at(n - 1);
+        const bool filling = n < a.ef;
+        {   // the first unused item behind it, and its adjacency one expansion early (a random HBM read: ~1 us)
+            const int fu2 = first_unused();
+            pre_ok = fu2 < lim;
+            const int node = pre_ok ? id_at(fu2) : -1;
+            pre_key = pre_ok ? key_at(fu2) : INFINITY;
+            if (pre_ok && node != pre_node) pre_v = load_adj0(node);
+            pre_node = node;
+        }
+        P = -1;
         lap(1);
-        if (m == 0) continue;
+        if (m == 0) {
+            if (pre_ok) {
+                P = pre_node;
+                Pv = pre_v;
+            }
+            continue;
+        }
         ndc += m;
         mw_barrier();  // B: distances of this expansion
         inflight = false;
         lap(3);
-
         // accept d < topKey || size < ef   (:240)
-        float dj = INFINITY;
-        int idj = -1;
-        bool acc = false;
-        if (lane < m) {
-            dj = nd[lane];
-            idj = nbr[lane];
-            acc = (dj < topKey) || (size0 < a.ef);
-        }
-        const u64 amask = __ballot(acc);
-        const int m2 = __popcll(amask);
-
+        dj = nd[lane];
+        idj = nbr[lane];
+        acc = (lane < m) & ((dj < topKey) | filling);
+        amask = BALLOT(acc);
+        m2 = __popcll(amask);
         // The next expansion, named before the merge.  pre_node is the first unused item of the array; the merge
         // moves it up by the number of accepted keys below it and puts nothing unused in front of it except those
         // accepted items.  So: no accepted key below pre_key -> pre_node is next (its position, unchanged, is
         // below ef); otherwise the closest accepted item is next (it lands in front of pre_node, hence below ef).
         // Equal keys leave the order to the merge: no early choice then.
         if (pre_ok) {
-            int P = -1, Pv = 0;
-            const u64 below = __ballot(acc && dj < pre_key);
-            const u64 equal = __ballot(acc && dj == pre_key);
+            const u64 below = BALLOT(acc & (dj < pre_key));
+            const u64 equal = BALLOT(acc & (dj == pre_key));
             if (!equal) {
                 if (!below) {
                     P = pre_node;
                     Pv = pre_v;
                 } else {
                     const float best = wave_min_f32(acc ? dj : INFINITY);
-                    const u64 bm = __ballot(acc && dj == best);
+                    const u64 bm = BALLOT(acc & (dj == best));
                     if (__popcll(bm) == 1) {
-                        P = __builtin_amdgcn_readlane(idj, __ffsll((long long)bm) - 1);
+                        P = __builtin_amdgcn_readlane(idj, (int)__builtin_ctzll(bm));
                         Pv = load_adj0(P);
                     }
                 }
             }
-            if (P >= 0) {
-                pipe_m = filter(Pv);
-                if (overflow) break;
-                pipe_node = P;
-                if (pipe_m > 0) {
-                    publish(pipe_m);
-                    inflight = true;
-                }
-            }
         }
         lap(4);
-        if (m2 == 0) continue;
-
-        // ascending order of the accepted items (std::sort, :251); ties keep list order
-        int rank = 0;
-        for (u64 mm = amask; mm;) {
-            const int j = __ffsll((long long)mm) - 1;
-            mm &= mm - 1;
-            const float dother = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dj), j));
-            rank += (dother < dj || (dother == dj && j < lane)) ? 1 : 0;
-        }
-        if (acc) {
-            sk[rank] = dj;
-            si[rank] = idj;
-        }
-        __builtin_amdgcn_wave_barrier();
-
-        // the merge of hnsw_search_body: all accepted items at once unless two keys involved are equal
-        bool tie = false;
-        float kreg[SA_EMAX];
-        int cntv[SA_EMAX];
-#pragma unroll
-        for (int e = 0; e < SA_EMAX; ++e) {
-            const int i = lane + 64 * e;
-            kreg[e] = (e * 64 < n && i < n) ? keys[i] : INFINITY;
-            cntv[e] = 0;
-        }
-        const float mykey = lane < m2 ? sk[lane] : INFINITY;
-        const int myid = lane < m2 ? si[lane] : -1;
-        int myless = 0;
-        for (int t = 0; t < m2; ++t) {
-            const float skt = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mykey), t));
-            int less = 0;
-#pragma unroll
-            for (int e = 0; e < SA_EMAX; ++e) {
-                if (e * 64 < n) {
-                    less += __popcll(__ballot(kreg[e] < skt));
-                    cntv[e] += (skt < kreg[e]) ? 1 : 0;
-                    tie |= (skt == kreg[e]);
-                }
-            }
-            if (lane == t) myless = less;
-        }
-        tie |= (lane + 1 < m2) && (mykey == __shfl_down(mykey, 1, 64));
-        if (!__any(tie)) {
-            int ireg[SA_EMAX];
-#pragma unroll
-            for (int e = 0; e < SA_EMAX; ++e) {
-                const int i = lane + 64 * e;
-                ireg[e] = (e * 64 < n && i < n) ? idu[i] : 0;
-            }
-            const int newn = n + m2 < a.cap ? n + m2 : a.cap;
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int e = 0; e < SA_EMAX; ++e) {
-                const int i = lane + 64 * e;
-                if (e * 64 < n && i < n && cntv[e] > 0) {
-                    const int np = i + cntv[e];
-                    if (np < newn) {
-                        keys[np] = kreg[e];
-                        idu[np] = ireg[e];
-                    }
-                }
-            }
-            if (lane < m2) {
-                const int np = myless + lane;
-                if (np < newn) {
-                    keys[np] = mykey;
-                    idu[np] = myid;
-                }
-            }
-            const int first = __builtin_amdgcn_readlane(myless, 0);
-            if (first < cursor) cursor = first;
-            n = newn;
-            __builtin_amdgcn_wave_barrier();
-        } else {
-            // SortArrBI::push_or_replace_non_empty_exp for each, in order (sort_arr_bi.h:159-199)
-            for (int t = 0; t < m2; ++t) {
-                const float key = sk[t];
-                const int id = si[t];
-                const float lastk = keys[n - 1];
-                if (lastk <= key) {
-                    if (n < a.cap) {
-                        if (lane == 0) {
-                            keys[n] = key;
-                            idu[n] = id;
-                        }
-                        n++;
-                    }
-                } else {
-                    int less = 0, leq = 0;
-#pragma unroll
-                    for (int e = 0; e < SA_EMAX; ++e) {
-                        if (e * 64 < n) {
-                            const int i = lane + 64 * e;
-                            const float kv = i < n ? keys[i] : INFINITY;
-                            less += __popcll(__ballot(kv < key));
-                            leq += __popcll(__ballot(kv <= key));
-                        }
-                    }
-                    int p = less;
-                    if (leq != less) {
-                        int curr = n - 1, prev = curr, dstep = 1;
-                        while (curr > 0 && keys[curr] > key) {
-                            prev = curr;
-                            curr -= dstep;
-                            dstep *= 2;
-                            if (dstep > curr) dstep = curr;
-                        }
-                        p = curr;
-                        for (int i = curr; i < prev && keys[i] < key; ++i) p = i + 1;
-                    }
-                    const int newn = n < a.cap ? n + 1 : a.cap;
-                    float rk[SA_EMAX];
-                    int ri[SA_EMAX];
-#pragma unroll
-                    for (int e = 0; e < SA_EMAX; ++e) {
-                        if (e * 64 < newn) {
-                            const int i = lane + 64 * e;
-                            if (i > p && i < newn) {
-                                rk[e] = keys[i - 1];
-                                ri[e] = idu[i - 1];
-                            }
-                        }
-                    }
-                    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                    for (int e = 0; e < SA_EMAX; ++e) {
-                        if (e * 64 < newn) {
-                            const int i = lane + 64 * e;
-                            if (i > p && i < newn) {
-                                keys[i] = rk[e];
-                                idu[i] = ri[e];
-                            }
-                        }
-                    }
-                    if (lane == 0) {
-                        keys[p] = key;
-                        idu[p] = id;
-                    }
-                    n = newn;
-                    if (p < cursor) cursor = p;  // :261-266
-                }
-                __builtin_amdgcn_wave_barrier();
-            }
-        }
-        lap(5);
     }
     // ---- release the gather waves (every published list is collected first) ----
     if (inflight) mw_barrier();  // B
-    publish(-1);
-    if (a.prof && lane == 0) {
-        for (int i = 0; i < 6; ++i) atomicAdd(&g_hnsw_mw_prof[i], (unsigned long long)pc[i]);
-        atomicAdd(&g_hnsw_mw_prof[6], 1ull);
+    ctl[0] = -1;
+    mw_barrier();  // A
+    if constexpr (PROF) {
+        if (lane == 0) {
+            for (int i = 0; i < 6; ++i) atomicAdd(&g_hnsw_mw_prof[i], (unsigned long long)pc[i]);
+            atomicAdd(&g_hnsw_mw_prof[6], 1ull);
+        }
     }
-    if (bad && lane == 0) atomicAdd(&g_hnsw_mw_prof[7], 1ull);
+    if (status == 2 && lane == 0) atomicAdd(&g_hnsw_mw_prof[7], 1ull);
 
     // ---- results: first k items, ties ordered by internal id (as hnsw_search_body) ----
-    const bool redo = overflow || bad;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        if (posv[e] < a.capa) {
+            keys[posv[e]] = kreg[e];
+            idu[posv[e]] = ireg[e];
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    const bool redo = status != 0;
     const int kk = redo ? 0 : (a.k < n ? a.k : n);
     for (int i = lane; i < a.k; i += 64) {
         if (i < kk) {
@@ -515,7 +540,7 @@ __device__ __forceinline__ void mw_control(const HnswArgs& a, const int q, float
     }
 }
 
-template <int SPACE, int SA_EMAX>
+template <int SPACE, int SA_EMAX, bool PROF>
 __global__ __launch_bounds__(MW_THREADS) void hnsw_search_mw_kernel(HnswArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const HnswDeviceGraph& g = a.g;
@@ -527,9 +552,7 @@ __global__ __launch_bounds__(MW_THREADS) void hnsw_search_mw_kernel(HnswArgs a) 
     float* qv = reinterpret_cast<float*>(idu + a.capa);      // [ldv]
     int* nbr = reinterpret_cast<int*>(qv + g.ldv);           // [64] rows of the frontier being gathered
     float* nd = reinterpret_cast<float*>(nbr + 64);          // [64] their distances
-    float* sk = nd + 64;                                     // [64] accepted keys, sorted
-    int* si = reinterpret_cast<int*>(sk + 64);               // [64] accepted ids
-    int* ctl = si + 64;                                      // [4]  rows in nbr[] (-1: the search is over)
+    int* ctl = reinterpret_cast<int*>(nd + 64);              // [4]  rows in nbr[] (-1: the search is over)
     uint32_t* table = reinterpret_cast<uint32_t*>(ctl + 4);  // [table_size]
 
     if (g.n == 0) {  // (uniform: every wave leaves)
@@ -570,7 +593,7 @@ __global__ __launch_bounds__(MW_THREADS) void hnsw_search_mw_kernel(HnswArgs a) 
         if (threadIdx.x == 0) ctl[0] = 0;
     }
     __syncthreads();
-    if (wave == 0) mw_control<SPACE, SA_EMAX>(a, q, keys, idu, qv, nbr, nd, sk, si, ctl, table, lane);
+    if (wave == 0) mw_control<SPACE, SA_EMAX, PROF>(a, q, keys, idu, nbr, nd, ctl, table, lane);
     else mw_gather_loop<SPACE>(a, qv, nbr, nd, ctl, wave - 1, lane);
 }
 
@@ -584,8 +607,11 @@ static hipError_t launch_mw_space(const HnswArgs& a, size_t lds, int sa_emax, hi
         hipLaunchKernelGGL(kern, dim3(a.nq), dim3(MW_THREADS), lds, s, a);
         return hipGetLastError();
     };
-    if (sa_emax <= 2) return go(hnsw_search_mw_kernel<SPACE, 2>);
-    return go(hnsw_search_mw_kernel<SPACE, 4>);
+    if constexpr (SPACE == SP_L2SQR) {
+        if (a.prof && sa_emax <= 2) return go(hnsw_search_mw_kernel<SPACE, 2, true>);
+    }
+    if (sa_emax <= 2) return go(hnsw_search_mw_kernel<SPACE, 2, false>);
+    return go(hnsw_search_mw_kernel<SPACE, 4, false>);
 }
 
 hipError_t launch_hnsw_search_mw(const HnswArgs& a, size_t lds_bytes, int sa_emax, hipStream_t s) {
