@@ -39,6 +39,6 @@ constexpr uint32_t HT_EMPTY = 0xFFFFFFFFu;  // free slot of the LDS visited tabl
 // (2 or 4).  Same results, bit for bit, as hnsw_search_kernel<SPACE, false, sa_emax, false>.
 hipError_t launch_hnsw_search_mw(const HnswArgs& a, size_t lds_bytes, int sa_emax, hipStream_t s);
 // control-wave phase cycles accumulated since the last call (NMSLIB_HNSW_PROF), then cleared
-void hnsw_mw_read_prof(unsigned long long out[8]);
+void hnsw_mw_read_prof(unsigned long long out[12]);
 
 }  // namespace gfxknn

@@ -1109,11 +1109,14 @@ hipError_t launch_hnsw_search_ex(const HnswDeviceGraph& g, const HnswSearchPlan&
         if (h[6])
             fprintf(stderr, "[hnsw_search] cycles/query: descent %.0f pick+adj %.0f visited %.0f gather %.0f accept %.0f insert %.0f\n",
                     h[0] / w, h[1] / w, h[2] / w, h[3] / w, h[4] / w, h[5] / w);
-        hnsw_mw_read_prof(h);
-        if (h[6])
-            fprintf(stderr, "[hnsw_search_mw] control-wave cycles/query: descent %.0f pick %.0f filter %.0f wait %.0f decide %.0f merge %.0f  (mispredicted %llu of %llu)\n",
-                    h[0] / (double)h[6], h[1] / (double)h[6], h[2] / (double)h[6], h[3] / (double)h[6], h[4] / (double)h[6],
-                    h[5] / (double)h[6], h[7], h[6]);
+        unsigned long long hm[12] = {0};
+        hnsw_mw_read_prof(hm);
+        if (hm[6]) {
+            const double wq = (double)hm[6];
+            fprintf(stderr, "[hnsw_search_mw] control-wave cycles/query: descent %.0f pick %.0f slow-pick %.0f wait %.0f accept %.0f name-next %.0f probe %.0f list+barrierA %.0f merge %.0f  (mispredicted %llu of %llu)\n",
+                    hm[0] / wq, hm[1] / wq, hm[2] / wq, hm[3] / wq, hm[8] / wq, hm[9] / wq, hm[10] / wq, hm[11] / wq, hm[5] / wq,
+                    hm[7], hm[6]);
+        }
         return pe;
     }
     switch (g.space) {

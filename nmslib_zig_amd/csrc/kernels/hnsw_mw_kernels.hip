@@ -32,7 +32,8 @@ constexpr int MW_MAX_EMAX = 4;                 // sorted array up to 256 items
 
 // [0] descent, [1] pick + scans, [2] filter + publish (not pipelined), [3] waiting for distances,
 // [4] accept + decision + pipelined filter, [5] merge, [6] queries, [7] mispredictions (must stay 0)
-__device__ unsigned long long g_hnsw_mw_prof[8];
+// [8] accept (LDS read + ballots), [9] naming the next node, [10] visited probe loop, [11] list + barrier A
+__device__ unsigned long long g_hnsw_mw_prof[12];
 
 // LDS traffic of this wave done, then the workgroup barrier (no vmcnt wait: an adjacency prefetch may be in flight)
 __device__ __forceinline__ void mw_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -65,11 +66,13 @@ __device__ __forceinline__ void mw_gather_loop(const HnswArgs& a, const float* q
     // (the guard only bounds the damage of a protocol error: a wave that ended lets s_barrier through)
     for (int guard = 0; guard < (1 << 26); ++guard) {
         mw_barrier();  // A: list published
+        // the row of the first round is read together with the count (the list is always padded to 64 valid ids)
+        int id = nbr[w * 8 + g8];
         const int m = __builtin_amdgcn_readfirstlane(ctl[0]);
         if (m < 0) break;
         for (int base = w * 8; base < m; base += 8 * MW_NW) {
             const int idx = base + g8;
-            const int id = nbr[idx];  // (the control wave pads the list to 64 entries with its last id)
+            if (base != w * 8) id = nbr[idx];
             const float* rp = rows + (size_t)id * g.ldv;
             float s0 = 0.f, s1 = 0.f, s2 = 0.f;
             auto fetch = [&](f32x4 (&bb)[4], int cb) __attribute__((always_inline)) {
@@ -79,7 +82,16 @@ __device__ __forceinline__ void mw_gather_loop(const HnswArgs& a, const float* q
                     bb[it] = *reinterpret_cast<const f32x4*>(rp + (d < dlast ? d : dlast));
                 }
             };
-            auto consume = [&](const f32x4 (&bb)[4], int cb) __attribute__((always_inline)) {
+            // a whole step of 128 floats: nothing to mask
+            auto consume_full = [&](const f32x4 (&bb)[4], int cb) __attribute__((always_inline)) {
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const f32x4 qq = *reinterpret_cast<const f32x4*>(qv + cb + sub * 4 + 32 * it);
+                    accum4<SPACE>(qq, bb[it], s0, s1, s2);
+                }
+            };
+            // the last, partial step: elements past the row contribute zeros on both sides (same sums, bit for bit)
+            auto consume_tail = [&](const f32x4 (&bb)[4], int cb) __attribute__((always_inline)) {
 #pragma unroll
                 for (int it = 0; it < 4; ++it) {
                     const int d = cb + sub * 4 + 32 * it;
@@ -96,12 +108,13 @@ __device__ __forceinline__ void mw_gather_loop(const HnswArgs& a, const float* q
             while (true) {
                 if (cb + 128 < g.ldv) {
                     fetch(nxt, cb + 128);
-                    consume(cur, cb);
+                    consume_full(cur, cb);
 #pragma unroll
                     for (int it = 0; it < 4; ++it) cur[it] = nxt[it];
                     cb += 128;
                 } else {
-                    consume(cur, cb);
+                    if (cb + 128 == g.ldv) consume_full(cur, cb);
+                    else consume_tail(cur, cb);
                     break;
                 }
             }
@@ -149,6 +162,16 @@ __device__ __forceinline__ void mw_control(const HnswArgs& a, const int q, float
     const uint32_t tmask = (uint32_t)a.table_size - 1u;
     const int tfull = a.table_size - (a.table_size >> 3);
 
+    long long pc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    long long pt = PROF ? (long long)__builtin_readcyclecounter() : 0;
+    auto lap = [&](int ph) __attribute__((always_inline)) {
+        if constexpr (PROF) {
+            const long long now = (long long)__builtin_readcyclecounter();
+            pc[ph] += now - pt;
+            pt = now;
+        }
+    };
+
     // visited filter of an adjacency list v (lane L: neighbour L; lane 63: the count): test-and-set in the LDS hash
     // (exact), the unvisited neighbours go to nbr[0..m), the rest of nbr[] is padded with the last of them, ctl[0] = m.
     // Wave-uniform probe loop: lanes that are done keep issuing a compare-and-swap that cannot match.
@@ -167,6 +190,7 @@ __device__ __forceinline__ void mw_control(const HnswArgs& a, const int q, float
             h = (h + 1) & tmask;
         }
         const bool isn = __builtin_amdgcn_inverse_ballot_w64(nm);
+        lap(10);
         const int m = __popcll(nm);
         if (m > 0) {
             const int lastid = __builtin_amdgcn_readlane(v, 63 - __clzll((long long)nm));
@@ -181,16 +205,6 @@ __device__ __forceinline__ void mw_control(const HnswArgs& a, const int q, float
         const int w = lane + 1 <= g.maxM0 ? lane + 1 : 0;
         return g.links0[(size_t)c * (g.maxM0 + 1) + w];
     };
-    long long pc[6] = {0, 0, 0, 0, 0, 0};
-    long long pt = PROF ? (long long)__builtin_readcyclecounter() : 0;
-    auto lap = [&](int ph) __attribute__((always_inline)) {
-        if constexpr (PROF) {
-            const long long now = (long long)__builtin_readcyclecounter();
-            pc[ph] += now - pt;
-            pt = now;
-        }
-    };
-
     // ---- entry point + greedy descent (hnsw_distfunc_opt.cc:168-198) ----
     int cur = g.enterpoint;
     nbr[lane] = cur;
@@ -425,7 +439,7 @@ __device__ __forceinline__ void mw_control(const HnswArgs& a, const int q, float
             mw_barrier();  // A
             inflight = true;
         }
-        lap(4);
+        lap(11);
         // ---- while they work: the merge of the previous expansion, then the pick of this one ----
         if (m2 > 0) merge(dj, idj, acc, amask, m2);
         m2 = 0;
@@ -469,6 +483,7 @@ __device__ __forceinline__ void mw_control(const HnswArgs& a, const int q, float
         acc = (lane < m) & ((dj < topKey) | filling);
         amask = BALLOT(acc);
         m2 = __popcll(amask);
+        lap(8);
         // The next expansion, named before the merge.  pre_node is the first unused item of the array; the merge
         // moves it up by the number of accepted keys below it and puts nothing unused in front of it except those
         // accepted items.  So: no accepted key below pre_key -> pre_node is next (its position, unchanged, is
@@ -491,7 +506,7 @@ __device__ __forceinline__ void mw_control(const HnswArgs& a, const int q, float
                 }
             }
         }
-        lap(4);
+        lap(9);
     }
     // ---- release the gather waves (every published list is collected first) ----
     if (inflight) mw_barrier();  // B
@@ -499,7 +514,8 @@ __device__ __forceinline__ void mw_control(const HnswArgs& a, const int q, float
     mw_barrier();  // A
     if constexpr (PROF) {
         if (lane == 0) {
-            for (int i = 0; i < 6; ++i) atomicAdd(&g_hnsw_mw_prof[i], (unsigned long long)pc[i]);
+            for (int i = 0; i < 12; ++i)
+                if (i != 6 && i != 7) atomicAdd(&g_hnsw_mw_prof[i], (unsigned long long)pc[i]);
             atomicAdd(&g_hnsw_mw_prof[6], 1ull);
         }
     }
@@ -629,8 +645,8 @@ hipError_t launch_hnsw_search_mw(const HnswArgs& a, size_t lds_bytes, int sa_ema
     }
 }
 
-void hnsw_mw_read_prof(unsigned long long out[8]) {
-    unsigned long long z[8] = {0};
+void hnsw_mw_read_prof(unsigned long long out[12]) {
+    unsigned long long z[12] = {0};
     (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_hnsw_mw_prof), sizeof(z));
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_hnsw_mw_prof), z, sizeof(z));
 }
