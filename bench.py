@@ -85,6 +85,8 @@ def parse():
     ap.add_argument("--index-extra", default="", help="hnsw: extra index parameters, k=v,k=v (experiments)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="queries in the CPU baseline sample (0 = auto)")
     ap.add_argument("--gt-sample", type=int, default=128, help="queries in the exact-ground-truth sample")
+    ap.add_argument("--dump", default="", help="rank 0 saves the ids / distances of the last timed step here (.npz): "
+                                                  "tests compare sharded and unsharded runs")
     return ap.parse_args()
 
 
@@ -337,6 +339,8 @@ def run_workload(a, name, cx):
 
     res_ids = (m_ids if world > 1 else d_ids).cpu().numpy()
     res_ds = (m_ds if world > 1 else d_ds).cpu().numpy()
+    if a.dump and rank == 0:
+        np.savez(a.dump, ids=res_ids, dists=res_ds)
     counters = idx.read_counters(nq) if method == "hnsw" else None
     stats = idx.stats()
     last_path = int(stats.get("last_path", 0))
@@ -530,8 +534,9 @@ def main():
     # --gpus N without a torchrun environment: launch the N ranks ourselves (before anything touches the GPU)
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         port = 29500 + (os.getpid() % 2000)
+        # ("--" ends torchrun's own options: it abbreviates, and "--n" would match its --nnodes)
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
-               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+               "--master-addr", "127.0.0.1", "--master-port", str(port), "--", os.path.abspath(__file__)] + sys.argv[1:]
         sys.exit(subprocess.call(cmd))
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))

@@ -687,17 +687,16 @@ nmslib_error_t nmslib_gpu_kernel_timing(nmslib_index_handle_t handle, int enable
 nmslib_error_t nmslib_gpu_get_stats(nmslib_index_handle_t handle, nmslib_gpu_stats_t* out) {
     if (!handle || !out) FAIL(NMSLIB_ERROR_INVALID_ARGUMENT, "Invalid arguments");
     Engine* e = H(handle)->engine;
-    out->upload_seconds = e->upload_seconds;
-    out->build_seconds = e->build_seconds;
-    out->hbm_bytes = e->hbm_bytes();
-    out->rows = e->size();
-    out->dim = e->dim();
-    out->shards = e->shard_count() ? e->shard_count() : 1;
-    out->last_path = (size_t)e->last_path;
-    out->fast_tiles = out->fast_tiles_precise = out->fast_tiles_fallback = 0;
-    out->hnsw_redone = 0;
+    std::memset(out, 0, sizeof(*out));
     return guarded(NMSLIB_ERROR_RUNTIME, "Failed to read statistics", [&] {
         std::lock_guard<std::mutex> lk(e->mu);
+        out->upload_seconds = e->upload_seconds;
+        out->build_seconds = e->build_seconds;
+        out->hbm_bytes = e->hbm_bytes();
+        out->rows = e->size();
+        out->dim = e->dim();
+        out->shards = e->shard_count() ? e->shard_count() : 1;
+        out->last_path = (size_t)e->last_path;
         e->fast_tile_counts(&out->fast_tiles, &out->fast_tiles_precise, &out->fast_tiles_fallback);
         out->hnsw_redone = e->hnsw_redone();
     });

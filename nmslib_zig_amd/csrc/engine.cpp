@@ -88,6 +88,10 @@ void* DevBuf::ensure(size_t bytes) {
     if (bytes == 0) bytes = 16;
     hip_check(hipMalloc(&p_, bytes), "hipMalloc");
     n_ = bytes;
+    // NMSLIB_GPU_POISON=<byte>: fill every new workspace with that byte, so that a kernel reading memory nobody wrote
+    // shows up in the tests instead of depending on what the allocator hands back
+    static const char* poison = getenv("NMSLIB_GPU_POISON");
+    if (poison) hip_check(hipMemset(p_, atoi(poison) & 0xFF, bytes), "poison");
     return p_;
 }
 void DevBuf::release() {
@@ -220,6 +224,11 @@ void Engine::reset() {
     dim_ = 0;  // a reset index accepts rows of another dimension
     centred_ = false;
     have_bf16_ = false;
+    last_path = 0;
+    fast_flags_ = nullptr;
+    fast_nqt_ = 0;
+    hnsw_fix_valid_ = false;
+    have_counters_ = false;
 }
 
 size_t Engine::memory_usage() const {
@@ -664,7 +673,7 @@ void Engine::build_graph_gpu() {
 
 void Engine::ensure_graph() {
     if (method_ != Method::Hnsw || !graph_dirty_) return;
-    if (use_gpu_build() || (!parent_ && resolve_shards() > 1)) {
+    if (use_gpu_build() || (!parent_ && (shards_.size() > 1 || (dirty_ && resolve_shards() > 1)))) {
         finalize();
         return;
     }
@@ -799,6 +808,13 @@ void Engine::finalize() {
     dirty_ = false;
 }
 
+// restores the calling thread's current device on every way out of a scope that visits other devices
+struct DeviceGuard {
+    int dev;
+    explicit DeviceGuard(int d) : dev(d) {}
+    ~DeviceGuard() { (void)hipSetDevice(dev); }
+};
+
 // ---------------------------------------------------------------------------------------------
 // Row shards behind one handle: shard s owns rows [s*n/S, (s+1)*n/S) on device (base + s) % count,
 // with its own workspaces, stream and (HNSW) graph.  A query batch goes to every shard; per-shard top-k lists are
@@ -820,8 +836,13 @@ int Engine::resolve_shards() const {
         return 1;  // finalize() reports the missing device
     }
     const size_t n = ids_.size();
-    if (want < 0) want = (int)std::min<size_t>((size_t)count, std::max<size_t>(1, n / 1000000));  // auto: 1M rows per shard
-    else if (want == 0) want = count;
+    if (want < 0) {
+        // automatic: the exact scan only -- sharded it returns the unsharded result bit for bit.  One HNSW graph per
+        // GPU changes ids and recall with the number of visible devices and cannot be saved in the reference's
+        // single-graph file, so HNSW is sharded only when gpu_shards / NMSLIB_GPU_SHARDS ask for it.
+        if (method_ != Method::Brute) return 1;
+        want = (int)std::min<size_t>((size_t)count, std::max<size_t>(1, n / 1000000));  // 1M rows per shard
+    } else if (want == 0) want = count;
     if ((size_t)want > n) want = (int)n;
     return std::max(1, want);
 }
@@ -885,6 +906,7 @@ void Engine::knn_sharded(const void* d_queries, size_t nq, size_t elem_count, si
     const size_t S = shards_.size();
     const size_t qbytes = nq * elem_count * elem_bytes();
     have_counters_ = false;
+    DeviceGuard guard(device_);  // an exception thrown by a shard must not leave this thread on the shard's device
     ws_sh_ids_.ensure(S * nq * k * 4);
     ws_sh_d_.ensure(S * nq * k * 4);
     hip_check(hipEventRecord(shard_ready_, stream), "hipEventRecord");  // the queries are ready on the caller's stream
@@ -910,8 +932,12 @@ void Engine::knn_sharded(const void* d_queries, size_t nq, size_t elem_count, si
                                      c.stream_),
                   "dists P2P");
         hip_check(hipEventRecord(shard_events_[s], c.stream_), "hipEventRecord");
+        // NMSLIB_GPU_SHARD_SERIAL=1 (diagnostics): one shard at a time instead of all shards' kernels side by side
+        static const bool serial = getenv("NMSLIB_GPU_SHARD_SERIAL") && atoi(getenv("NMSLIB_GPU_SHARD_SERIAL"));
+        if (serial) hip_check(hipStreamSynchronize(c.stream_), "shard (serial)");
     }
     hip_check(hipSetDevice(device_), "hipSetDevice");
+    last_path = shards_[0]->last_path;  // every shard takes the same path for the same batch shape
     for (size_t s = 0; s < S; ++s) hip_check(hipStreamWaitEvent(stream, shard_events_[s], 0), "hipStreamWaitEvent");
     hip_check(launch_merge_topk_ex(ws_sh_d_.as<float>(), ws_sh_ids_.as<int32_t>(), nq * k, (int)S, (int)nq, (int)k, d_dists,
                                    d_ids, d_cnt, d_ids_.as<int32_t>(), stream),
@@ -1370,7 +1396,7 @@ static void rd(std::istream& i, T& v) {
 
 void Engine::save(const std::string& path, bool save_data) {
     if (!created_) throw EngineError(Err::InvalidArgument, "Index not built");
-    if (method_ == Method::Hnsw && !loaded_graph_ && resolve_shards() > 1)
+    if (method_ == Method::Hnsw && !loaded_graph_ && (shards_.size() > 1 || (dirty_ && resolve_shards() > 1)))
         throw EngineError(Err::DataIO, "a sharded HNSW index holds one graph per GPU and has no single-file form; "
                                        "build with gpu_shards=1 to save it in the reference's format");
     ensure_graph();  // persistence is host-side: no device needed

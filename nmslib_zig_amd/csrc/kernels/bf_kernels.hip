@@ -19,6 +19,8 @@
 // Survivors are appended to a per-(query, split) buffer in HBM (L2-resident); when a buffer
 // nears capacity the owning wave sorts it in LDS, keeps k', and raises the threshold.
 #include <cstdio>
+#include <type_traits>
+#include <vector>
 #include <cstdlib>
 
 #include "common.cuh"
@@ -1373,6 +1375,16 @@ struct BfScanF32Args {
 // take, and two query groups per wave spilled at 256 registers.)
 // (SAMPLE = true, a sample pass with near-exact scores, is not instantiated any more: the sample pass runs
 //  bf_scan_bf16_kernel<MODE, true, 2> and the threshold kernel accounts for its error.)
+// Fragment registers of the scan kernels are PINNED to physical VGPRs.  A fragment is the target of an asynchronous
+// ds_read (inline asm) and becomes valid at a counted s_waitcnt (inline asm naming the same register, so that the MFMAs
+// behind it cannot move above it).  With ordinary "=v"/"+v" operands the register allocator may give the wait's
+// operand another register than the read's and insert the copy IN FRONT of the wait -- a copy of bytes that have not
+// arrived (seen in bf_scan_bf16_kernel<.., 1, 8>'s last block: rows listed at random, a neighbour lost in ~8 % of the
+// batches at 70k rows x 600 queries).  One fixed register tuple per slot leaves nothing to copy.
+#define BF_FRAG_RD(REGS, var, addr) asm volatile("ds_read_b128 %0, %1" : "={" REGS "}"(var) : "v"(addr) : "memory")
+#define BF_FRAG_RD_OFF(REGS, var, addr, off) \
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "={" REGS "}"(var) : "v"(addr), "n"(off) : "memory")
+
 template <int MODE, bool SAMPLE, int QG>
 __global__ __launch_bounds__(256) void bf_scan_f32_kernel(BfScanF32Args a) {
     constexpr int NW = 4;
@@ -1527,8 +1539,31 @@ __global__ __launch_bounds__(256) void bf_scan_f32_kernel(BfScanF32Args a) {
     bool have_pv = false;
     const uint32_t lds0 = (uint32_t)(uintptr_t)(lptr_t)smem;
     auto load_frag = [&](uint32_t rp, int kc) __attribute__((always_inline)) {
-        asm volatile("ds_read_b128 %0, %1" : "=v"(fh[kc % 4]) : "v"(rp + foff[kc]) : "memory");
-        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fl[kc % 4]) : "v"(rp + foff[kc]), "n"(kHalfBytes) : "memory");
+        const uint32_t ad = rp + foff[kc];
+        switch (kc % 4) {   // (kc is a constant after unrolling)
+            case 0: BF_FRAG_RD("v[208:211]", fh[0], ad); BF_FRAG_RD_OFF("v[224:227]", fl[0], ad, kHalfBytes); break;
+            case 1: BF_FRAG_RD("v[212:215]", fh[1], ad); BF_FRAG_RD_OFF("v[228:231]", fl[1], ad, kHalfBytes); break;
+            case 2: BF_FRAG_RD("v[216:219]", fh[2], ad); BF_FRAG_RD_OFF("v[232:235]", fl[2], ad, kHalfBytes); break;
+            default: BF_FRAG_RD("v[220:223]", fh[3], ad); BF_FRAG_RD_OFF("v[236:239]", fl[3], ad, kHalfBytes); break;
+        }
+    };
+    // the counted wait that makes slot kc % 4 (and, with INIT, the start values) valid
+    auto wait_frag = [&](auto cnt_tag, int kc, bool with_init) __attribute__((always_inline)) {
+        constexpr int N = decltype(cnt_tag)::value;
+#define BF_W3(STR)                                                                                                       \
+        switch (kc % 4) {                                                                                                \
+            case 0:                                                                                                      \
+                if (with_init) asm volatile(STR : "+{v[208:211]}"(fh[0]), "+{v[224:227]}"(fl[0]), "+{v[240:255]}"(iv));  \
+                else asm volatile(STR : "+{v[208:211]}"(fh[0]), "+{v[224:227]}"(fl[0]));                                 \
+                break;                                                                                                   \
+            case 1: asm volatile(STR : "+{v[212:215]}"(fh[1]), "+{v[228:231]}"(fl[1])); break;                           \
+            case 2: asm volatile(STR : "+{v[216:219]}"(fh[2]), "+{v[232:235]}"(fl[2])); break;                           \
+            default: asm volatile(STR : "+{v[220:223]}"(fh[3]), "+{v[236:239]}"(fl[3])); break;                          \
+        }
+        if constexpr (N == 0) { BF_W3("s_waitcnt lgkmcnt(0)") }
+        else if constexpr (N == 4) { BF_W3("s_waitcnt lgkmcnt(4)") }
+        else { BF_W3("s_waitcnt lgkmcnt(8)") }
+#undef BF_W3
     };
     auto load_init = [&](uint32_t ax) __attribute__((always_inline)) {
         // register 4j+i of half h = row 8j + 4h + i of the block.  The four reads fill ONE 16-register tuple (fixed
@@ -1591,18 +1626,15 @@ __global__ __launch_bounds__(256) void bf_scan_f32_kernel(BfScanF32Args a) {
                 // reads of step kc+2, then the wait for step kc's fragments (+ the start values at kc = 0)
                 if (kc + 2 < 8) {
                     load_frag(rp, kc + 2);
-                    if (kc == 0 && MODE == SC_L2)
-                        asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(fh[0]), "+v"(fl[0]), "+{v[240:255]}"(iv));
-                    else
-                        asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(fh[kc % 4]), "+v"(fl[kc % 4]));
+                    wait_frag(std::integral_constant<int, 4>{}, kc, kc == 0 && MODE == SC_L2);
                 } else if (has_next) {
                     if (kc == 6) load_init(nax);
                     load_frag(nrp, kc + 2 - 8);
                     // in flight behind step kc's fragments: step 7's (kc = 6 only), the start values, the next block's
-                    if (kInitReads) asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(fh[kc % 4]), "+v"(fl[kc % 4]));
-                    else asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(fh[kc % 4]), "+v"(fl[kc % 4]));
+                    if (kInitReads) wait_frag(std::integral_constant<int, 8>{}, kc, false);
+                    else wait_frag(std::integral_constant<int, 4>{}, kc, false);
                 } else {
-                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fh[kc % 4]), "+v"(fl[kc % 4]));
+                    wait_frag(std::integral_constant<int, 0>{}, kc, false);
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 if (kc == 0) {
@@ -1823,7 +1855,52 @@ __global__ __launch_bounds__(NW * 64) void bf_scan_bf16_kernel(BfScanF32Args a) 
     unsigned long long trig_pend = 0ull;
     const uint32_t lds0 = (uint32_t)(uintptr_t)(lptr_t)smem;
     auto load_frag = [&](uint32_t rp, int kc) __attribute__((always_inline)) {
-        asm volatile("ds_read_b128 %0, %1" : "=v"(fh[kc % 4]) : "v"(rp + foff[kc]) : "memory");
+        const uint32_t ad = rp + foff[kc];
+        if constexpr (NW == 4) {
+            switch (kc % 4) {   // (kc is a constant after unrolling)
+                case 0: BF_FRAG_RD("v[224:227]", fh[0], ad); break;
+                case 1: BF_FRAG_RD("v[228:231]", fh[1], ad); break;
+                case 2: BF_FRAG_RD("v[232:235]", fh[2], ad); break;
+                default: BF_FRAG_RD("v[236:239]", fh[3], ad); break;
+            }
+        } else {   // (two waves per SIMD share the register file: stay low)
+            switch (kc % 4) {
+                case 0: BF_FRAG_RD("v[96:99]", fh[0], ad); break;
+                case 1: BF_FRAG_RD("v[100:103]", fh[1], ad); break;
+                case 2: BF_FRAG_RD("v[104:107]", fh[2], ad); break;
+                default: BF_FRAG_RD("v[108:111]", fh[3], ad); break;
+            }
+        }
+    };
+    // the counted wait that makes slot kc % 4 (and, with with_init, the start values) valid
+    auto wait_frag = [&](auto cnt_tag, int kc, bool with_init) __attribute__((always_inline)) {
+        constexpr int N = decltype(cnt_tag)::value;
+#define BF_W1(STR)                                                                                              \
+        if constexpr (NW == 4) {                                                                                \
+            switch (kc % 4) {                                                                                   \
+                case 0:                                                                                         \
+                    if (with_init) asm volatile(STR : "+{v[224:227]}"(fh[0]), "+{v[240:255]}"(iv));             \
+                    else asm volatile(STR : "+{v[224:227]}"(fh[0]));                                            \
+                    break;                                                                                      \
+                case 1: asm volatile(STR : "+{v[228:231]}"(fh[1])); break;                                      \
+                case 2: asm volatile(STR : "+{v[232:235]}"(fh[2])); break;                                      \
+                default: asm volatile(STR : "+{v[236:239]}"(fh[3])); break;                                     \
+            }                                                                                                   \
+        } else {                                                                                                \
+            switch (kc % 4) {                                                                                   \
+                case 0:                                                                                         \
+                    if (with_init) asm volatile(STR : "+{v[96:99]}"(fh[0]), "+{v[112:127]}"(iv));               \
+                    else asm volatile(STR : "+{v[96:99]}"(fh[0]));                                              \
+                    break;                                                                                      \
+                case 1: asm volatile(STR : "+{v[100:103]}"(fh[1])); break;                                      \
+                case 2: asm volatile(STR : "+{v[104:107]}"(fh[2])); break;                                      \
+                default: asm volatile(STR : "+{v[108:111]}"(fh[3])); break;                                     \
+            }                                                                                                   \
+        }
+        if constexpr (N == 0) { BF_W1("s_waitcnt lgkmcnt(0)") }
+        else if constexpr (N == 2) { BF_W1("s_waitcnt lgkmcnt(2)") }
+        else { BF_W1("s_waitcnt lgkmcnt(6)") }
+#undef BF_W1
     };
     auto load_init = [&](uint32_t ax) __attribute__((always_inline)) {
         if constexpr (MODE == SC_L2) {
@@ -1861,16 +1938,14 @@ __global__ __launch_bounds__(NW * 64) void bf_scan_bf16_kernel(BfScanF32Args a) 
                 // the next block's start values) stay in flight
                 if (kc + 2 < 8) {
                     load_frag(rp, kc + 2);
-                    if (kc == 0 && MODE == SC_L2 && NW == 4) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(fh[0]), "+{v[240:255]}"(iv));
-                    else if (kc == 0 && MODE == SC_L2) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(fh[0]), "+{v[112:127]}"(iv));
-                    else asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(fh[kc % 4]));
+                    wait_frag(std::integral_constant<int, 2>{}, kc, kc == 0 && MODE == SC_L2);
                 } else if (has_next) {
                     if (kc == 6) load_init(nax);
                     load_frag(nrp, kc + 2 - 8);
-                    if (kInitReads) asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(fh[kc % 4]));
-                    else asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(fh[kc % 4]));
+                    if (kInitReads) wait_frag(std::integral_constant<int, 6>{}, kc, false);
+                    else wait_frag(std::integral_constant<int, 2>{}, kc, false);
                 } else {
-                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fh[kc % 4]));
+                    wait_frag(std::integral_constant<int, 0>{}, kc, false);
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 // The previous block's scores are checked one group per kEvery K-steps, in two halves: step gc * kEvery
@@ -2616,6 +2691,56 @@ __global__ void merge_topk_kernel(const float* dists_in, const int32_t* ids_in, 
     }
 }
 
+// The same merge when nshards * k keys do not fit LDS (k in the thousands): every per-shard list is already ascending
+// in (distance, id), so an item's place in the merged order is its own index plus, for every other list, the number
+// of keys below it there (bisection; keys are unique because ids are).  Items ranked below k write themselves.
+__global__ void merge_topk_big_kernel(const float* dists_in, const int32_t* ids_in, size_t shard_stride, int nshards,
+                                      int nq, int k, float* dists_out, int32_t* ids_out, int32_t* cnt_out,
+                                      const int32_t* ext_ids) {
+    const int q = blockIdx.x;
+    auto key_of = [&](int s, int j) -> u64 {
+        const size_t off = (size_t)s * shard_stride + (size_t)q * k + j;
+        const int32_t id = ids_in[off];
+        return id >= 0 ? (((u64)f32_ord(dists_in[off]) << 32) | (uint32_t)id) : ~0ull;
+    };
+    for (int i = threadIdx.x; i < k; i += blockDim.x) {  // (slots no list reaches stay "no result")
+        ids_out[(size_t)q * k + i] = -1;
+        dists_out[(size_t)q * k + i] = INFINITY;
+    }
+    __syncthreads();
+    int valid = 0;
+    for (int i = threadIdx.x; i < nshards * k; i += blockDim.x) {
+        const int s = i / k, j = i - s * k;
+        const u64 key = key_of(s, j);
+        if (key == ~0ull) continue;
+        valid++;
+        int rank = j;
+        for (int t = 0; t < nshards && rank < k; ++t) {
+            if (t == s) continue;
+            int lo = 0, hi = k;
+            while (lo < hi) {  // number of keys of list t below `key` (missing entries compare as +inf)
+                const int mid = (lo + hi) >> 1;
+                if (key_of(t, mid) < key) lo = mid + 1;
+                else hi = mid;
+            }
+            rank += lo;
+        }
+        if (rank < k) {
+            const int32_t id = (int32_t)(uint32_t)key;
+            ids_out[(size_t)q * k + rank] = ext_ids ? ext_ids[id] : id;
+            dists_out[(size_t)q * k + rank] = ord_f32((uint32_t)(key >> 32));
+        }
+    }
+    if (cnt_out) {
+        __shared__ int total;
+        if (threadIdx.x == 0) total = 0;
+        __syncthreads();
+        atomicAdd(&total, valid);
+        __syncthreads();
+        if (threadIdx.x == 0) cnt_out[q] = total < k ? total : k;
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // Host side
 // ---------------------------------------------------------------------------------------
@@ -3276,6 +3401,37 @@ hipError_t launch_bf_f32_fast(const BfF32Fast& f, int space, int n, int dim, int
     hipLaunchKernelGGL(bf_rerank_f32_list_kernel, dim3(nq), dim3(256), f.lds_rerank, s, r);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
+    {   // NMSLIB_GPU_DEBUG & 2048: checksums of the intermediate buffers of this batch (determinism screens)
+        static const int dbg = getenv("NMSLIB_GPU_DEBUG") ? atoi(getenv("NMSLIB_GPU_DEBUG")) : 0;
+        if (dbg & 2048) {
+            (void)hipStreamSynchronize(s);
+            auto sum = [&](const void* d, size_t bytes) -> unsigned long long {
+                std::vector<uint32_t> h(bytes / 4);
+                (void)hipMemcpy(h.data(), d, bytes, hipMemcpyDeviceToHost);
+                unsigned long long x = 1469598103934665603ull;
+                for (uint32_t v : h) x = (x ^ v) * 1099511628211ull;
+                return x;
+            };
+            std::vector<int> cnt((size_t)f.qpad * f.nsplit * 2);
+            (void)hipMemcpy(cnt.data(), list_cnt, cnt.size() * 4, hipMemcpyDeviceToHost);
+            std::vector<uint32_t> lst((size_t)f.qpad * f.nsplit * 2 * f.caph);
+            (void)hipMemcpy(lst.data(), list, lst.size() * 4, hipMemcpyDeviceToHost);
+            unsigned long long lx = 1469598103934665603ull;   // only the entries that exist
+            long long rows = 0;
+            for (size_t i = 0; i < cnt.size(); ++i) {
+                rows += cnt[i];
+                int have = 0;
+                for (int j = 0; j < f.caph && have < cnt[i]; ++j) {
+                    const uint32_t e = lst[i * f.caph + j];
+                    lx = (lx ^ e) * 1099511628211ull;
+                    have += __builtin_popcount(e & 0xffffu);
+                }
+            }
+            fprintf(stderr, "[f32fast] top8 %016llx thr %016llx thr1 %016llx flags %016llx cnt %016llx list %016llx rows %lld\n",
+                    sum(top8, (size_t)f.qpad * f.s_nsplit * 2 * 8 * 4), sum(thr, (size_t)f.qpad * 4), sum(thr1, (size_t)f.qpad * 4),
+                    sum(tile_fail, (size_t)f.nqt * 8), sum(list_cnt, cnt.size() * 4), lx, rows);
+        }
+    }
     // 4. fallback: the adaptive f32 kernel + its re-rank (verified for l2, with its exact tail) for flagged query tiles
     //    (256 * qg queries = 2 * qg of its tiles)
     return launch_bf_adaptive_f32(f.fallback, space, dim, k, base_orig, sel_rows, aux, queries_orig, queries_sel, nullptr, bmax,
@@ -3353,6 +3509,11 @@ hipError_t launch_merge_topk_ex(const float* dists_in, const int32_t* ids_in, si
                                 hipStream_t s) {
     const int P = host_next_pow2(nshards * k < 2 ? 2 : nshards * k);
     const size_t lds = (size_t)P * 8;
+    if (lds > 64 * 1024) {  // beyond the LDS sort: rank every item by bisection in the other lists
+        hipLaunchKernelGGL(merge_topk_big_kernel, dim3(nq), dim3(256), 0, s, dists_in, ids_in, shard_stride, nshards, nq, k,
+                           dists_out, ids_out, cnt_out, ext_ids);
+        return hipGetLastError();
+    }
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(merge_topk_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;

@@ -599,3 +599,33 @@ def test_fast_paths_with_batches_larger_than_one_slice():
         np.testing.assert_array_equal(ids[lo:lo + 50], i2)
         np.testing.assert_array_equal(ds[lo:lo + 50], d2)
     idx.close()
+
+
+@pytest.mark.parametrize("shape", ["f32_256q_tiles", "f32_512q_tiles", "f32_cosine", "u8"])
+def test_fast_paths_are_deterministic(shape):
+    """Race screen (round 3): the same batch thirty times on the same index must return the same bits, and the
+    oracle's answer.  Found with it: in bf_scan_bf16_kernel<.., QG=1, NW=8> (256-query tiles, i.e. batches of 256..1023
+    queries) the compiler had placed a register copy of an LDS fragment IN FRONT of the s_waitcnt that makes it valid;
+    the last 32-row block of every row split was scored from bytes that had not arrived -- rows listed at random, a true
+    neighbour lost in ~8 % of the batches at 70k rows x 600 queries, on one GPU and behind 2-shard handles alike.  The
+    fragments now live in pinned registers (BF_FRAG_RD)."""
+    if shape == "u8":
+        X, Q, k, space = refio.s_sift_like(140003, 21), refio.s_sift_like(600, 22), 100, "l2sqr_sift"
+    else:
+        n, nq = (70001, 600) if shape != "f32_512q_tiles" else (100003, 1100)
+        X, Q, k = refio.s_lowrank(n, 128, 21), refio.s_lowrank(nq, 128, 22), 10
+        space = "cosinesimil" if shape == "f32_cosine" else "l2"
+    idx = make_index(space, "seq_search", X)
+    first = idx.knnQueryBatch(Q, k)
+    assert idx.stats()["last_path"] in (1, 3), "the fast path did not run"
+    for _ in range(30):
+        r = idx.knnQueryBatch(Q, k)
+        np.testing.assert_array_equal(r[0], first[0])
+        np.testing.assert_array_equal(r[1].view(np.uint32), first[1].view(np.uint32))
+    opos, odist, _ = orc.seq_search(space, X, Q[:48], k)
+    if space == "l2sqr_sift":
+        np.testing.assert_array_equal(first[0][:48], opos)
+        np.testing.assert_array_equal(first[1][:48], odist)
+    else:
+        assert (first[0][:48] == opos).mean() >= 0.999 and close_rel(first[1][:48], odist)
+    idx.close()

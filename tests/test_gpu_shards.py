@@ -100,3 +100,70 @@ def test_sharded_fast_paths_equal_unsharded(space):
     np.testing.assert_array_equal(small[1], a[1][:40])
     one.close()
     two.close()
+
+
+def test_sharded_k_beyond_the_lds_merge():
+    """nshards * k keys that do not fit the LDS sort of merge_topk: the HBM rank-by-bisection merge takes
+    over; brute force k = 3000 on 3 shards and HNSW algoType=old with ef = k = 2500 on 2 shards, against the
+    unsharded index (exact scan: bit for bit; HNSW: each shard is its own graph, so the exact scan is the yardstick)."""
+    n, nq = 20011, 9
+    X, Q = refio.s_lowrank(n, 48, 31), refio.s_lowrank(nq, 48, 32)
+    X[500:520] = X[7]                                  # ties that straddle the shard border
+    X[n // 3 - 2:n // 3 + 2] = X[7]
+    ext = np.random.default_rng(2).permutation(n).astype(np.int32) + 5
+    one = make_index("l2", "seq_search", X, ext, gpu_shards=1)
+    many = make_index("l2", "seq_search", X, ext, gpu_shards=3)
+    a, b = one.knnQueryBatch(Q, 3000), many.knnQueryBatch(Q, 3000)
+    for x, y in zip(a, b):
+        np.testing.assert_array_equal(x, y)
+    many.close()
+    h = make_index("l2", "hnsw", X, ext, M=12, efConstruction=60, gpu_shards=2)
+    h.setQueryTimeParams(efSearch=2500, algoType="old")
+    ids, ds, cnt = h.knnQueryBatch(Q, 2500)
+    assert (cnt == 2500).all() and np.all(np.diff(ds, axis=1) >= 0)
+    gi, gd, _ = one.knnQueryBatch(Q, 2500)
+    rec = np.mean([len(set(x) & set(y)) / 2500 for x, y in zip(ids.tolist(), gi.tolist())])
+    assert rec >= 0.98, rec
+    h.close()
+    one.close()
+
+
+def test_hnsw_is_not_auto_sharded(monkeypatch):
+    """without gpu_shards / NMSLIB_GPU_SHARDS an HNSW index is ONE graph whatever the number of visible
+    GPUs (ids, recall and saveIndex must not depend on the machine); the exact scan may shard by itself."""
+    for v in ("NMSLIB_GPU_SHARDS", "NMSLIB_GPU_DEVICE", "LOCAL_RANK"):
+        monkeypatch.delenv(v, raising=False)
+    X = refio.s_lowrank(3000, 32, 3)
+    idx = make_index("l2", "hnsw", X, M=8, efConstruction=40)
+    assert idx.stats()["shards"] == 1
+    idx.close()
+
+
+def test_shards_on_distinct_devices_when_the_node_has_them():
+    """The peer-to-peer leg of Engine::knn_sharded (hipMemcpyPeerAsync of queries and per-shard lists, events across
+    devices) only runs with >= 2 visible GPUs: skipped on a one-GPU box, exercised the first time hardware allows."""
+    ndev = nz.lib().nmslib_gpu_device_count()
+    if ndev < 2:
+        pytest.skip("one visible GPU: all shards share it (covered by the tests above)")
+    shards = min(ndev, 4)
+    n, nq, k = 60000, 300, 10
+    X, Q = refio.s_lowrank(n, 64, 41), refio.s_lowrank(nq, 64, 42)
+    one = make_index("l2", "seq_search", X, gpu_shards=1)
+    many = make_index("l2", "seq_search", X, gpu_shards=shards)
+    assert many.stats()["shards"] == shards
+    a, b = one.knnQueryBatch(Q, k), many.knnQueryBatch(Q, k)
+    for x, y in zip(a, b):
+        np.testing.assert_array_equal(x, y)
+    U, UQ = refio.s_sift_like(n, 43), refio.s_sift_like(nq, 44)
+    one8 = make_index("l2sqr_sift", "seq_search", U, gpu_shards=1)
+    many8 = make_index("l2sqr_sift", "seq_search", U, gpu_shards=shards)
+    a, b = one8.knnQueryBatch(UQ, 50), many8.knnQueryBatch(UQ, 50)
+    for x, y in zip(a, b):
+        np.testing.assert_array_equal(x, y)
+    h = make_index("l2", "hnsw", X, M=16, efConstruction=100, gpu_shards=shards)
+    h.setQueryTimeParams(efSearch=64)
+    ids, ds, cnt = h.knnQueryBatch(Q, k)
+    gi = one.knnQueryBatch(Q, k)[0]
+    assert np.mean([len(set(x) & set(y)) / k for x, y in zip(ids.tolist(), gi.tolist())]) >= 0.95
+    for i in (one, many, one8, many8, h):
+        i.close()
