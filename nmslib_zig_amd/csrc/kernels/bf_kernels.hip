@@ -1604,37 +1604,36 @@ __global__ __launch_bounds__(256) void bf_scan_f32_kernel(BfScanF32Args a) {
     };
     constexpr int kInitReads = MODE == SC_L2 ? 4 : 0;
     const uint32_t ring_a = lds0, aux_a = lds0 + kRing * kStageBytes + 16 * h;   // LDS byte addresses
-    if (nstages > 0) {
-        load_init(aux_a);
-        load_frag(ring_a, 0);
-        load_frag(ring_a, 1);
-    }
+    // (unconditional, also for a split without tiles: a branch here makes `iv` a merge of two values, and the compiler
+    //  keeps such merges alive with copies -- of registers whose read is still in flight)
+    load_init(aux_a);
+    load_frag(ring_a, 0);
+    load_frag(ring_a, 1);
     for (int t = 0; t < nstages; ++t) {
         const uint32_t th_ = ring_a + (t % kRing) * kStageBytes;   // hi tile; lo tile kHalfBytes behind
         const float* axs = auxr + (t % kAuxRing) * BF_BN + 4 * h;
         const int row0 = r_begin + t * stage_rows;
-        const bool more = t + 1 < nstages;
 #pragma unroll
         for (int blk = 0; blk < 2; ++blk) {
             const uint32_t rp = th_ + blk * 32 * 256;
             // the block behind this one: block 1 of this stage, or block 0 of the next stage
             const uint32_t nrp = blk == 0 ? th_ + 32 * 256 : ring_a + ((t + 1) % kRing) * kStageBytes;
             const uint32_t nax = blk == 0 ? aux_a + ((t % kAuxRing) * BF_BN + 32) * 4 : aux_a + (((t + 1) % kAuxRing) * BF_BN) * 4;
-            const bool has_next = blk == 0 || more;
 #pragma unroll
             for (int kc = 0; kc < 8; ++kc) {
                 // reads of step kc+2, then the wait for step kc's fragments (+ the start values at kc = 0)
                 if (kc + 2 < 8) {
                     load_frag(rp, kc + 2);
                     wait_frag(std::integral_constant<int, 4>{}, kc, kc == 0 && MODE == SC_L2);
-                } else if (has_next) {
+                } else {
+                    // (also in the very last block, where the "next block" is a ring slot nobody filled: the same
+                    //  straight-line code everywhere.  A branch around these asm statements makes the compiler split
+                    //  the fragments' live ranges with copies on either side of the waits -- copies of bytes in flight.)
                     if (kc == 6) load_init(nax);
                     load_frag(nrp, kc + 2 - 8);
                     // in flight behind step kc's fragments: step 7's (kc = 6 only), the start values, the next block's
                     if (kInitReads) wait_frag(std::integral_constant<int, 8>{}, kc, false);
                     else wait_frag(std::integral_constant<int, 4>{}, kc, false);
-                } else {
-                    wait_frag(std::integral_constant<int, 0>{}, kc, false);
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 if (kc == 0) {
@@ -1680,6 +1679,8 @@ __global__ __launch_bounds__(256) void bf_scan_f32_kernel(BfScanF32Args a) {
             }
         }
     }
+    // (the prefetches the last block issued for a block that does not exist: their registers are free only now)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (have_pv) finish_check(block_max(QG - 1, pv_ax), acc[QG - 1], QG - 1, pv_ax, pv_row0);  // the last block's last group
 #pragma unroll
     for (int g = 0; g < QG; ++g) {
@@ -1916,22 +1917,20 @@ __global__ __launch_bounds__(NW * 64) void bf_scan_bf16_kernel(BfScanF32Args a) 
     };
     constexpr int kInitReads = MODE == SC_L2 ? 4 : 0;
     const uint32_t ring_a = lds0, aux_a = lds0 + kRing * kStageBytes + 16 * h;
-    if (nstages > 0) {
-        load_init(aux_a);
-        load_frag(ring_a, 0);
-        load_frag(ring_a, 1);
-    }
+    // (unconditional, also for a split without tiles: a branch here makes `iv` a merge of two values, and the compiler
+    //  keeps such merges alive with copies -- of registers whose read is still in flight)
+    load_init(aux_a);
+    load_frag(ring_a, 0);
+    load_frag(ring_a, 1);
     for (int t = 0; t < nstages; ++t) {
         const uint32_t th_ = ring_a + (t % kRing) * kStageBytes;
         const float* axs = auxr + (t % kAuxRing) * BF_BN + 4 * h;
         const int row0 = r_begin + t * stage_rows;
-        const bool more = t + 1 < nstages;
 #pragma unroll
         for (int blk = 0; blk < 2; ++blk) {
             const uint32_t rp = th_ + blk * 32 * 256;
             const uint32_t nrp = blk == 0 ? th_ + 32 * 256 : ring_a + ((t + 1) % kRing) * kStageBytes;
             const uint32_t nax = blk == 0 ? aux_a + ((t % kAuxRing) * BF_BN + 32) * 4 : aux_a + (((t + 1) % kAuxRing) * BF_BN) * 4;
-            const bool has_next = blk == 0 || more;
 #pragma unroll
             for (int kc = 0; kc < 8; ++kc) {
                 // the read of step kc+2, then the wait for step kc's fragment: at most the reads of steps kc+1, kc+2 (and
@@ -1939,13 +1938,12 @@ __global__ __launch_bounds__(NW * 64) void bf_scan_bf16_kernel(BfScanF32Args a) 
                 if (kc + 2 < 8) {
                     load_frag(rp, kc + 2);
                     wait_frag(std::integral_constant<int, 2>{}, kc, kc == 0 && MODE == SC_L2);
-                } else if (has_next) {
+                } else {
+                    // (also in the very last block: see bf_scan_f32_kernel)
                     if (kc == 6) load_init(nax);
                     load_frag(nrp, kc + 2 - 8);
                     if (kInitReads) wait_frag(std::integral_constant<int, 6>{}, kc, false);
                     else wait_frag(std::integral_constant<int, 2>{}, kc, false);
-                } else {
-                    wait_frag(std::integral_constant<int, 0>{}, kc, false);
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 // The previous block's scores are checked one group per kEvery K-steps, in two halves: step gc * kEvery
@@ -1999,6 +1997,8 @@ __global__ __launch_bounds__(NW * 64) void bf_scan_bf16_kernel(BfScanF32Args a) 
             }
         }
     }
+    // (the prefetches the last block issued for a block that does not exist: their registers are free only now)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (have_pv) {   // the last block (nstages > 0: it was block 1 of its stage)
 #pragma unroll
         for (int g = 0; g < QG; ++g) {

@@ -31,6 +31,7 @@ struct HnswArgs {
     int32_t* fix_list;
     int32_t* fix_count;
     int fix_mode;
+    int no_pipe;  // NMSLIB_HNSW_PIPE=0: the one-wave kernel without its software pipeline (diagnostics)
 };
 
 constexpr uint32_t HT_EMPTY = 0xFFFFFFFFu;  // free slot of the LDS visited table

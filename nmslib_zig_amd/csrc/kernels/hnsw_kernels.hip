@@ -323,7 +323,7 @@ __device__ __forceinline__ void hnsw_search_body(const HnswArgs& a, char* smem, 
             if (sk[0] <= pre_key) {  // guess (B)
                 pre2_node = si[0];
                 pre2_v = load_adj(pre2_node);
-            } else if (!WIDE && pre_ok) {
+            } else if (!WIDE && pre_ok && !a.no_pipe) {
                 // Every accepted key is larger than the key of the array's next unused item: that item (pre_node,
                 // adjacency already here) IS the next expansion, whatever the merge below does to the positions
                 // behind it.  Run its visited filter now and request its rows; the merge overlaps the gather.
@@ -408,7 +408,11 @@ __device__ __forceinline__ void hnsw_search_body(const HnswArgs& a, char* smem, 
                 }
                 if (lane == t) myless = less;
             }
-            tie |= (lane + 1 < m2) && (mykey == __shfl_down(mykey, 1, 64));
+            // (the shuffle runs in ALL lanes: under the short-circuit `&&` it sat in a divergent branch, lane m2-2 read
+            //  its inactive neighbour as 0 and a tie between the two largest accepted keys went unnoticed -- found in
+            //  round 3 by tests/test_gpu_hnsw_mw.py against the oracle)
+            const float next_key = __shfl_down(mykey, 1, 64);
+            tie |= (lane + 1 < m2) & (mykey == next_key);
             if (!__any(tie)) {
                 int ireg[SA_EMAX];
     #pragma unroll
@@ -1087,6 +1091,7 @@ hipError_t launch_hnsw_search_ex(const HnswDeviceGraph& g, const HnswSearchPlan&
     a.fix_list = t_fix_list;
     a.fix_count = t_fix_count;
     a.fix_mode = (p.table_size == 0) ? t_fix_mode : 0;
+    a.no_pipe = getenv("NMSLIB_HNSW_PIPE") ? atoi(getenv("NMSLIB_HNSW_PIPE")) == 0 : 0;
     static const int prof = getenv("NMSLIB_HNSW_PROF") ? atoi(getenv("NMSLIB_HNSW_PROF")) : 0;
     a.prof = (prof && !query_rows) ? 1 : 0;
     a.nq = p.nq;

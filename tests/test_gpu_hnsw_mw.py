@@ -61,7 +61,7 @@ def test_multiwave_ties_follow_the_reference_placement():
     for ef, k in ((10, 10), (64, 10), (128, 50)):
         idx.setQueryTimeParams(efSearch=ef)
         opos, odist, ocnt, ondc, ohops = g.search(Q, k, ef)
-        for mode in ("2",):
+        for mode in ("2", "0"):
             r = _search(idx, Q, k, mode)
             np.testing.assert_array_equal(r[0], opos)
             np.testing.assert_array_equal(r[1], odist)          # small integers: exact in f32
