@@ -77,7 +77,9 @@ def parse():
     ap.add_argument("--k", type=int, default=None)
     ap.add_argument("--ef", type=int, default=128)
     ap.add_argument("--ef-sweep", default="", help="hnsw / cos768: extra efSearch values measured on the same index, e.g. 256,512,1000")
-    ap.add_argument("--rank", type=int, default=64, help="cos768: latent rank of the synthetic rows")
+    ap.add_argument("--rank", type=int, default=16, help="cos768 / cos768x: latent rank of the synthetic rows (16: the recall "
+                                                         "set, recall@10 ~0.99 at efS=128; 64: the stress set, ~0.45 at 1M rows "
+                                                         "for the reference's graph too -- tests/golden/c5_ref_1m768.json)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--index-cache", default="", help="hnsw, 1 GPU: save the built index here / load it if present")
     ap.add_argument("--gpu-build", type=int, default=-1, help="hnsw: 1 = batched GPU construction, 0 = host, -1 = library default")
@@ -355,15 +357,19 @@ def run_workload(a, name, cx):
         return None
 
     # ---- roofline of the dominant kernel (this rank's launches; HIP events on the launch stream) ---------
-    kern_s = kern_ms / 1e3 / max(1, launches)
+    # every interval recorded inside the timed loop belongs to one of its steps: a sliced batch (or a SearchOld batch
+    # that was answered again with larger workspaces) has several per step, and all of them are the kernel's time
+    kern_s = kern_ms / 1e3 / max(1, a.steps)
     rows_local = hi - lo
     if method == "hnsw":
         ndc, hops, hops_up = (c.astype(np.float64) for c in counters)
         # bytes/query = ndc*D*4 + hops0*(maxM0+1)*4 + hops_up*(maxM+1)*4 + ndc (visited)
         alg_bytes = float((ndc * dim * 4 + hops * 33 * 4 + hops_up * 17 * 4 + ndc).sum())
         roof = {"bound": "hbm", "achieved": round(alg_bytes / kern_s / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                "kernel": "hnsw_search_kernel", "ndc_per_query": round(float(ndc.mean()), 1),
-                "hops_per_query": round(float(hops.mean()), 1)}
+                "kernel": ("hnsw_search_mw_kernel" if nq <= 2048 and a.ef <= 256 and os.environ.get("NMSLIB_HNSW_MW", "1") != "0"
+                           else ("hnsw_search_old_kernel" if a.ef >= 1000 else "hnsw_search_kernel")),
+                "ndc_per_query": round(float(ndc.mean()), 1), "hops_per_query": round(float(hops.mean()), 1),
+                "kernel_launches_per_step": round(launches / max(1, a.steps), 2)}
     elif u8:
         ops = 2.0 * nq * rows_local * 128
         roof = {"bound": "mfma", "achieved": round(ops / kern_s / 1e12, 2), "peak": PEAK_I8_MFMA_TOPS, "unit": "TOP/s",
@@ -398,7 +404,8 @@ def run_workload(a, name, cx):
     roof["kernel_ms"] = round(kern_s * 1e3, 4)
     roof["traffic"] = None
     tr = os.path.join(ROOT, "profiles", "traffic.json")   # HBM bytes/launch from a separate rocprofv3 --pmc pass
-    if os.path.exists(tr) and n == 1_000_000 and world == 1 and dim == WORKLOADS[name]["dim"] and not a.space:
+    std_shape = ((n == 1_000_000) if name != "cos768x" else (a.rows_per_gpu == 1_000_000 and a.rank == 16 and nq == 8192))
+    if os.path.exists(tr) and std_shape and world == 1 and dim == WORKLOADS[name]["dim"] and not a.space and a.ef == 128:
         try:
             tj = json.load(open(tr))
             roof["traffic"] = tj.get(name)     # per workload: the same kernel moves other bytes on another shape
@@ -406,6 +413,19 @@ def run_workload(a, name, cx):
                 roof["traffic_source"] = tj.get("source")
         except Exception:
             pass
+    if method == "hnsw":
+        roof["algorithmic_bytes"] = int(alg_bytes)
+        if roof["traffic"]:
+            # rows that many queries of a batch visit are served by L2 / MALL: the bytes that really crossed the HBM
+            # interface are the measured ones, and that is the fraction of the HBM peak the kernel holds
+            roof["hbm_gbs_measured"] = round(roof["traffic"] / kern_s / 1e9, 1)
+            roof["frac_hbm_measured"] = round(roof["traffic"] / kern_s / 1e9 / PEAK_HBM_GBS, 4)
+            if roof["traffic"] < 0.9 * alg_bytes:
+                roof["note"] = ("achieved / frac count the algorithmic bytes (SURVEY.md 8d); "
+                                f"{100 * (1 - roof['traffic'] / alg_bytes):.0f} % of them were cache hits: frac_hbm_measured is "
+                                "the share of the HBM peak")
+    # the dominant kernel cannot take longer than the step that contains it
+    roof["consistent"] = bool(kern_s * 1e3 <= elapsed / a.steps * 1e3 * 1.02)
 
     out = {
         "metric": {"sift": f"queries/sec @ recall@{k}, {n} x 128-D u8 l2sqr_sift, batch={nq}",
@@ -457,9 +477,10 @@ def run_workload(a, name, cx):
             kms, kl = idx.kernel_timing(enable=False, collect=True)
             c2 = [c.astype(np.float64) for c in idx.read_counters(nq)]
             ab = float((c2[0] * dim * 4 + c2[1] * 33 * 4 + c2[2] * 17 * 4 + c2[0]).sum())
-            ks = kms / 1e3 / max(1, kl)
+            ks = kms / 1e3 / max(1, a.steps)
             sweep.append({"ef": ef2, "value": round(a.steps * nq / el2, 1), "ms_per_step": round(el2 / a.steps * 1e3, 4),
-                          "kernel_ms": round(ks * 1e3, 4), "hbm_gbs": round(ab / ks / 1e9, 1),
+                          "kernel_ms": round(ks * 1e3, 4), "kernel_launches_per_step": round(kl / max(1, a.steps), 2),
+                          "consistent": bool(ks * 1e3 <= el2 / a.steps * 1e3 * 1.02), "hbm_gbs": round(ab / ks / 1e9, 1),
                           "frac": round(ab / ks / 1e9 / PEAK_HBM_GBS, 4), "ndc_per_query": round(float(c2[0].mean()), 1),
                           "_ids": d_ids.cpu().numpy().copy()})
         idx.setQueryTimeParams(efSearch=a.ef)
@@ -481,6 +502,8 @@ def run_workload(a, name, cx):
         out["host_entry"] = {"entry": "nmslib_knn_query_batch (host pointers, PCIe inside the call)",
                              "ms_per_step": round(th * 1e3, 4), "queries_per_s": round(nq / th, 1),
                              "matches_device_entry": bool(np.array_equal(h_ids, res_ids))}
+        # what a caller of the reference's own ABI (lib.zig, C) gets, beside `value` (queries resident in HBM)
+        out["value_host_entry"] = round(nq / th, 1)
     idx.close()
 
     # ---- recall against an independent exact ground truth + the CPU baseline ---------------------------------

@@ -33,7 +33,11 @@ nmslib_error_t nmslib_gpu_finalize(nmslib_index_handle_t index);
 /* Batched k-NN with queries already in device memory.
  *   d_queries : [query_count][elem_count] float32 (dense) or uint8 (l2sqr_sift), row-major
  *   d_ids / d_dists / d_counts : outputs in device memory (d_counts may be NULL)
- *   stream    : hipStream_t (NULL = default stream); the call only enqueues work.
+ *   stream    : hipStream_t (NULL = default stream); the call only enqueues work -- with ONE exception: HNSW queries
+ *               that the reference answers with SearchOld (algoType=old, or the default hybrid with efSearch >= 1000,
+ *               hnsw.cc:724) read a per-query status word back and wait for the stream before returning (queues that
+ *               outgrew their workspace are re-run with larger ones, at most twice).  Every other path -- brute force,
+ *               both fast paths, SearchV1Merge incl. its visited-table overflow -- never blocks the caller.
  * Replaces the per-query loop of nmslib_knn_query_batch (nmslib_c.cpp:1015-1023). */
 nmslib_error_t nmslib_gpu_knn_query_batch_device(nmslib_index_handle_t index,
                                                  const void* d_queries, size_t query_count,

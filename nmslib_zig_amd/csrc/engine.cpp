@@ -1075,7 +1075,8 @@ void Engine::knn_brute(const void* d_queries, size_t nq, size_t k, int32_t* d_id
         if (f.use) {
             const int ldb = ldb_;
             ws_qpad_.ensure((size_t)f.qpad * ldb * 4);
-            hip_check(launch_pad_rows(d_queries, (int)nq, dim_eff, ws_qpad_.ptr(), f.qpad, ldb, 4, stream), "pad queries");
+            // (uncentred rows: padding happens inside the fast path's one preparation kernel)
+            if (centred_) hip_check(launch_pad_rows(d_queries, (int)nq, dim_eff, ws_qpad_.ptr(), f.qpad, ldb, 4, stream), "pad queries");
             const float* qsel = ws_qpad_.as<float>();
             if (centred_) {
                 ws_qsel_.ensure((size_t)f.qpad * ldb * 4);
@@ -1107,7 +1108,8 @@ void Engine::knn_brute(const void* d_queries, size_t nq, size_t k, int32_t* d_id
                                          d_bf_hi_.ptr(), d_bf_lo_.ptr(), d_auxp_.as<float>(), bmax_, bres_, ws_qpad_.as<float>(), qsel, qh, ql,
                                          ws_u8_cand_.as<float>(), ws_cand_.as<unsigned long long>(), ws_cnt_.as<int>(), thr,
                                          ws_u8_list_.as<uint32_t>(), ws_u8_listcnt_.as<int>(), tile_fail, ws_flags_.as<int>(),
-                                         d_ids_.as<int32_t>(), d_ids, d_dists, d_cnt, eb, ee, stream),
+                                         d_ids_.as<int32_t>(), d_ids, d_dists, d_cnt, eb, ee, stream,
+                                         centred_ ? nullptr : static_cast<const float*>(d_queries), centred_ ? nullptr : ws_qpad_.as<float>()),
                       "bf_f32_fast");
             last_path = 1;
             fast_flags_ = tile_fail;

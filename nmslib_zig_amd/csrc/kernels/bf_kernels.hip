@@ -2035,6 +2035,34 @@ __global__ void split_bf16_kernel(const float* src, int rows, int rows_pad, int 
     }
 }
 
+// Query preparation of the float fast path in ONE launch (round 3; was pad_rows + split_bf16 + four fillBuffers):
+//   raw != null: queries [nq][dim] -> padded f32 copy pad_out [qpad][ld] (zeros beyond nq / dim) and its bf16 split;
+//   raw == null: `sel` [qpad][ld] (already padded, centred) -> bf16 split only;
+//   and the words every later kernel of the batch expects to find cleared: the fast path's tile flags, the verified
+//   adaptive path's flags, both shared-threshold regions of the fallback selections.
+__global__ void bf_f32_prep_kernel(const float* raw, int nq, int dim, const float* sel, int qpad, int ld, float* pad_out,
+                                   __bf16* hi, __bf16* lo, int* clr0, int n0, int* clr1, int n1, uint32_t* clr2, size_t n2) {
+    const size_t gtid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, gsz = (size_t)gridDim.x * blockDim.x;
+    const size_t total = (size_t)qpad * 128;
+    for (size_t i = gtid; i < total; i += gsz) {
+        const size_t r = i >> 7;
+        const int c = (int)(i & 127);
+        float v;
+        if (raw) {
+            v = (r < (size_t)nq && c < dim) ? raw[r * dim + c] : 0.f;
+            if (c < ld) pad_out[r * ld + c] = v;
+        } else {
+            v = c < dim ? sel[r * ld + c] : 0.f;
+        }
+        const __bf16 hh = (__bf16)v;
+        hi[i] = hh;
+        lo[i] = (__bf16)(v - (float)hh);
+    }
+    for (size_t i = gtid; i < (size_t)n0; i += gsz) clr0[i] = 0;
+    for (size_t i = gtid; i < (size_t)n1; i += gsz) clr1[i] = 0;
+    for (size_t i = gtid; i < n2; i += gsz) clr2[i] = 0u;
+}
+
 // Error bound of the one-product score q_hi . b_hi of one query against any row (first wave of the workgroup; result
 // in every lane):  |q.b - q^.b^| <= |q - q^||b| + |q^||b - b^|  with the ACTUAL rounding residual of this query and the
 // largest residual of the rows (bres; relative to |b| for the cosine score, where bscale = 1), plus the f32 accumulation
@@ -2883,11 +2911,14 @@ hipError_t launch_bf_select_f32(const BfPlan& p, int space, const float* base, c
 
 hipError_t launch_bf_select_f32_ex(const BfPlan& p, int space, const float* base, const float* aux,
                                    const float* queries_padded, const float* qaux_cosc, unsigned long long* cand,
-                                   int* cand_cnt, const int* tile_fail, int fail_group, hipStream_t s) {
-    // per-query shared thresholds live behind the survivor counts; cleared for every batch
+                                   int* cand_cnt, const int* tile_fail, int fail_group, hipStream_t s, bool cleared) {
+    // per-query shared thresholds live behind the survivor counts; cleared for every batch (by the caller's prep
+    // kernel when `cleared`)
     uint32_t* gthr = reinterpret_cast<uint32_t*>(cand_cnt + (size_t)p.qpad * p.nsplit);
-    hipError_t me = hipMemsetAsync(gthr, 0, ((size_t)p.qpad + (size_t)p.qpad * p.nsplit) * 4, s);
-    if (me != hipSuccess) return me;
+    if (!cleared) {
+        hipError_t me = hipMemsetAsync(gthr, 0, ((size_t)p.qpad + (size_t)p.qpad * p.nsplit) * 4, s);
+        if (me != hipSuccess) return me;
+    }
     BfArgs a = make_args(p, base, aux, queries_padded, cand, cand_cnt, gthr);
     a.tile_fail = tile_fail;
     a.fail_group = fail_group;
@@ -2915,10 +2946,15 @@ hipError_t launch_bf_select_direct_f32(const BfPlan& p, int space, const float* 
 // SP_L2 here = squared differences summed by the VALU on the ORIGINAL rows (the exact tail of the verified l2 path)
 hipError_t launch_bf_select_direct_f32_ex(const BfPlan& p, int space, const float* base, const float* queries_padded,
                                           unsigned long long* cand, int* cand_cnt, const int* tile_fail, int fail_group,
-                                          hipStream_t s) {
+                                          hipStream_t s, bool cleared_second_region) {
+    const size_t gwords = (size_t)p.qpad + (size_t)p.qpad * p.nsplit;
     uint32_t* gthr = reinterpret_cast<uint32_t*>(cand_cnt + (size_t)p.qpad * p.nsplit);
-    hipError_t me = hipMemsetAsync(gthr, 0, ((size_t)p.qpad + (size_t)p.qpad * p.nsplit) * 4, s);
-    if (me != hipSuccess) return me;
+    if (cleared_second_region) {
+        gthr += gwords;   // its own region, cleared at the start of the batch together with the first (bf_f32_prep_kernel)
+    } else {
+        hipError_t me = hipMemsetAsync(gthr, 0, gwords * 4, s);
+        if (me != hipSuccess) return me;
+    }
     BfArgs a = make_args(p, base, nullptr, queries_padded, cand, cand_cnt, gthr);
     a.tile_fail = tile_fail;
     a.fail_group = fail_group;
@@ -3028,19 +3064,23 @@ hipError_t launch_bf_adaptive_f32(const BfPlan& p, int space, int dim, int k, co
                                   const float* aux, const float* queries_orig, const float* queries_sel,
                                   const float* qaux_cosc, float bmax, unsigned long long* cand, int* cand_cnt, int* flags,
                                   const int32_t* ext_ids, int32_t* out_ids, float* out_dists, int32_t* out_cnt,
-                                  const int* gate, int gate_tiles, hipStream_t s) {
-    hipError_t e = launch_bf_select_f32_ex(p, space, sel_rows, aux, queries_sel, qaux_cosc, cand, cand_cnt, gate, gate_tiles, s);
+                                  const int* gate, int gate_tiles, hipStream_t s, bool cleared) {
+    // cleared: the caller's prep kernel zeroed `flags` and both shared-threshold regions at the start of the batch
+    hipError_t e = launch_bf_select_f32_ex(p, space, sel_rows, aux, queries_sel, qaux_cosc, cand, cand_cnt, gate, gate_tiles, s,
+                                           cleared);
     if (e != hipSuccess) return e;
     const bool verify = space == SP_L2 && flags != nullptr && bmax > 0.f;
     if (!verify)
         return launch_bf_rerank_ex(p, space, dim, k, base_orig, queries_orig, cand, cand_cnt, ext_ids, out_ids, out_dists,
                                    out_cnt, gate, gate_tiles * BF_TQ, s);
-    e = hipMemsetAsync(flags, 0, (size_t)p.nqt * 4, s);
-    if (e != hipSuccess) return e;
+    if (!cleared) {
+        e = hipMemsetAsync(flags, 0, (size_t)p.nqt * 4, s);
+        if (e != hipSuccess) return e;
+    }
     e = launch_bf_rerank_verify(p, space, dim, k, base_orig, queries_orig, cand, cand_cnt, ext_ids, out_ids, out_dists,
                                 out_cnt, gate, gate_tiles * BF_TQ, flags, queries_sel, bmax, s);
     if (e != hipSuccess) return e;
-    e = launch_bf_select_direct_f32_ex(p, SP_L2, base_orig, queries_orig, cand, cand_cnt, flags, 1, s);
+    e = launch_bf_select_direct_f32_ex(p, SP_L2, base_orig, queries_orig, cand, cand_cnt, flags, 1, s, cleared);
     if (e != hipSuccess) return e;
     return launch_bf_rerank_ex(p, space, dim, k, base_orig, queries_orig, cand, cand_cnt, ext_ids, out_ids, out_dists,
                                out_cnt, flags, BF_TQ, s);
@@ -3308,11 +3348,23 @@ hipError_t launch_bf_f32_fast(const BfF32Fast& f, int space, int n, int dim, int
                               void* q_hi, void* q_lo, float* top8, unsigned long long* cand_fb, int* cnt_fb, float* thr,
                               uint32_t* list, int* list_cnt, int* tile_fail, int* flags_fb, const int32_t* ext_ids,
                               int32_t* out_ids, float* out_dists, int32_t* out_cnt, hipEvent_t scan_begin,
-                              hipEvent_t scan_end, hipStream_t s) {
+                              hipEvent_t scan_end, hipStream_t s, const float* queries_raw, float* queries_pad_out) {
     float* thr1 = thr + f.qpad;
     int* precise = tile_fail + f.nqt;
-    hipError_t e = launch_split_bf16(queries_sel, f.qpad, f.qpad, ldb, dim, q_hi, q_lo, nullptr, 0.f, nullptr, s);
-    if (e != hipSuccess) return e;
+    hipError_t e;
+    {   // pad (when the caller passes the raw queries) + bf16 split + every clear of the batch
+        const BfPlan& fb = f.fallback;
+        uint32_t* gthr = reinterpret_cast<uint32_t*>(cnt_fb + (size_t)fb.qpad * fb.nsplit);
+        const size_t gwords = 2 * ((size_t)fb.qpad + (size_t)fb.qpad * fb.nsplit);
+        size_t work = (size_t)f.qpad * 128 > gwords ? (size_t)f.qpad * 128 : gwords;
+        size_t grid = (work + 255) / 256;
+        if (grid > 2048) grid = 2048;
+        hipLaunchKernelGGL(bf_f32_prep_kernel, dim3((unsigned)grid), dim3(256), 0, s, queries_raw, nq, dim, queries_sel, f.qpad,
+                           ldb, queries_pad_out, static_cast<__bf16*>(q_hi), static_cast<__bf16*>(q_lo), tile_fail, 2 * f.nqt,
+                           flags_fb, fb.nqt, gthr, gwords);
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
     auto scan = [&](const BfScanF32Args& sa, bool sample, int terms, int grid) -> hipError_t {
         const size_t lds = terms == 1 ? f.lds_scan1 : f.lds_scan;
         if (f.mode == 0) return launch_scan_f32_mode<SC_L2>(sa, sample, terms, f.qg, grid, lds, s);
@@ -3336,8 +3388,7 @@ hipError_t launch_bf_f32_fast(const BfF32Fast& f, int space, int n, int dim, int
     sa.top8 = top8;
     e = scan(sa, true, 1, 8 * sa.nqt * (f.s_nsplit / 8));
     if (e != hipSuccess) return e;
-    e = hipMemsetAsync(tile_fail, 0, (size_t)f.nqt * 8, s);   // fallback flags + precise flags
-    if (e != hipSuccess) return e;
+    // (fallback flags + precise flags: cleared by the prep kernel)
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(bf_f32_threshold_kernel),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)f.lds_thr);
     if (e != hipSuccess) return e;
@@ -3435,7 +3486,8 @@ hipError_t launch_bf_f32_fast(const BfF32Fast& f, int space, int n, int dim, int
     // 4. fallback: the adaptive f32 kernel + its re-rank (verified for l2, with its exact tail) for flagged query tiles
     //    (256 * qg queries = 2 * qg of its tiles)
     return launch_bf_adaptive_f32(f.fallback, space, dim, k, base_orig, sel_rows, aux, queries_orig, queries_sel, nullptr, bmax,
-                                  cand_fb, cnt_fb, flags_fb, ext_ids, out_ids, out_dists, out_cnt, tile_fail, 2 * f.qg, s);
+                                  cand_fb, cnt_fb, flags_fb, ext_ids, out_ids, out_dists, out_cnt, tile_fail, 2 * f.qg, s,
+                                  /*cleared=*/true);
 }
 
 hipError_t launch_row_aux_f32(const float* base, int n, int ldb, int dim, int space, float* aux,

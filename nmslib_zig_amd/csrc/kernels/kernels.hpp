@@ -43,7 +43,9 @@ BfPlan bf_make_plan(int n, int dim, int nq, int k, bool is_u8, int qpad_multiple
 inline size_t bf_cand_elems(const BfPlan& p) { return (size_t)p.qpad * p.nsplit * p.cap; }
 // per-(query,split) survivor counts, then the per-query shared thresholds (gthr), then the
 // per-(query,split) counted bounds (gq)
-inline size_t bf_cnt_elems(const BfPlan& p) { return 2 * (size_t)p.qpad * p.nsplit + (size_t)p.qpad; }
+// (a second gthr/gq region behind the first: the exact-tail selection of the verified l2 path gets its own, so that one
+//  clear at the start of a batch serves both selections -- see bf_f32_prep_kernel)
+inline size_t bf_cnt_elems(const BfPlan& p) { return 3 * (size_t)p.qpad * p.nsplit + 2 * (size_t)p.qpad; }
 
 // Row padding for the f32 device copy: multiple of 8 floats (two 16-byte half-wave loads).
 inline int f32_row_stride(int dim) { return (dim + 7) & ~7; }
@@ -113,7 +115,7 @@ hipError_t launch_bf_u8_fast(const BfU8Fast& f, int n, int nq, int k, const uint
 
 hipError_t launch_bf_select_f32_ex(const BfPlan& p, int space, const float* base, const float* aux,
                                    const float* queries_padded, const float* qaux_cosc, unsigned long long* cand,
-                                   int* cand_cnt, const int* tile_fail, int fail_group, hipStream_t s);
+                                   int* cand_cnt, const int* tile_fail, int fail_group, hipStream_t s, bool cleared = false);
 
 // f32 fast path for large batches at D <= 128 (bf_kernels.hip: split-bf16 MFMA selection with sample-fixed thresholds,
 // exact f32 re-rank with verification, adaptive fallback).  Exact like the adaptive path.
@@ -149,14 +151,14 @@ hipError_t launch_bf_f32_fast(const BfF32Fast& f, int space, int n, int dim, int
                               void* q_hi, void* q_lo, float* top8, unsigned long long* cand_fb, int* cnt_fb, float* thr,
                               uint32_t* list, int* list_cnt, int* tile_fail, int* flags_fb, const int32_t* ext_ids, int32_t* out_ids,
                               float* out_dists, int32_t* out_cnt, hipEvent_t scan_begin, hipEvent_t scan_end,
-                              hipStream_t s);
+                              hipStream_t s, const float* queries_raw = nullptr, float* queries_pad_out = nullptr);
 
 // The adaptive f32 path end to end (selection, re-rank; l2: verification + exact tail).  flags: [p.nqt] ints.
 hipError_t launch_bf_adaptive_f32(const BfPlan& p, int space, int dim, int k, const float* base_orig, const float* sel_rows,
                                   const float* aux, const float* queries_orig, const float* queries_sel,
                                   const float* qaux_cosc, float bmax, unsigned long long* cand, int* cand_cnt, int* flags,
                                   const int32_t* ext_ids, int32_t* out_ids, float* out_dists, int32_t* out_cnt,
-                                  const int* gate, int gate_tiles, hipStream_t s);
+                                  const int* gate, int gate_tiles, hipStream_t s, bool cleared = false);
 hipError_t launch_bf_rerank_verify(const BfPlan& p, int space, int dim, int k, const void* base,
                                    const void* queries_padded, const unsigned long long* cand,
                                    const int* cand_cnt, const int32_t* ext_ids, int32_t* out_ids,
@@ -164,7 +166,7 @@ hipError_t launch_bf_rerank_verify(const BfPlan& p, int space, int dim, int k, c
                                    int* verify_flags, const float* queries_sel, float bmax, hipStream_t s);
 hipError_t launch_bf_select_direct_f32_ex(const BfPlan& p, int space, const float* base, const float* queries_padded,
                                           unsigned long long* cand, int* cand_cnt, const int* tile_fail, int fail_group,
-                                          hipStream_t s);
+                                          hipStream_t s, bool cleared_second_region = false);
 // Direct (VALU) selection for spaces with no inner-product form (l1, linf).
 hipError_t launch_bf_select_direct_f32(const BfPlan& p, int space, const float* base,
                                        const float* queries_padded, unsigned long long* cand,

@@ -629,3 +629,50 @@ def test_fast_paths_are_deterministic(shape):
     else:
         assert (first[0][:48] == opos).mean() >= 0.999 and close_rel(first[1][:48], odist)
     idx.close()
+
+
+def _golden3():
+    import hashlib
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_v3.npz"))
+
+    def check(name, a):
+        h = np.frombuffer(hashlib.sha256(np.ascontiguousarray(a).tobytes()).digest(), np.uint8)
+        assert np.array_equal(h, g[name]), f"{name}: regenerated input differs from the one the fixture was made from"
+    return g, check
+
+
+def test_full_size_c2_independent_queries_equal_the_reference():
+    """BASELINE config 2 at full size with the bench's own queries (S-lowrank seeds 42 / 43: NOT base rows -- no
+    distance-0 self match, ordinary gaps between ranks): the first 64 queries against the reference's own sequential
+    scan (tests/golden/golden_v3.npz, generated by gen_golden_v3.py from oracle/_ref).  ids exact, distances 1e-5."""
+    g, check = _golden3()
+    X, Q = refio.s_lowrank(1_000_000, 128, 42), refio.s_lowrank(1024, 128, 43)
+    check("c2_base_sha", X)
+    check("c2_queries_sha", Q)
+    idx = make_index("l2", "seq_search", X)
+    ids, ds, cnt = idx.knnQueryBatch(Q, 10)
+    st = idx.stats()
+    assert st["last_path"] == 1 and st["fast_tiles_fallback"] == 0, st       # the path the bench line is measured on
+    np.testing.assert_array_equal(ids[:64], g["c2_ids"])
+    assert close_rel(ds[:64], g["c2_dists"])
+    # the same 64 queries as their own small batch (adaptive f32 kernel): same rows, same floats
+    ids_s, ds_s, _ = idx.knnQueryBatch(Q[:64], 10)
+    np.testing.assert_array_equal(ids_s, ids[:64])
+    np.testing.assert_array_equal(ds_s, ds[:64])
+    idx.close()
+
+
+def test_full_size_c4_independent_queries_equal_the_reference():
+    """BASELINE config 4 at full size (1M x 128 u8, k = 100, batch 4096; S-sift-like seeds 44 / 45): the first 32
+    queries against the reference's sequential scan -- integer distances identical, ids identical modulo tie groups."""
+    from tests.gpuutil import ids_match_modulo_ties
+    g, check = _golden3()
+    U, UQ = refio.s_sift_like(1_000_000, 44), refio.s_sift_like(4096, 45)
+    check("c4_base_sha", U)
+    check("c4_queries_sha", UQ)
+    idx = make_index("l2sqr_sift", "seq_search", U)
+    ids, ds, cnt = idx.knnQueryBatch(UQ, 100)
+    assert idx.stats()["last_path"] == 3
+    np.testing.assert_array_equal(ds[:32], g["c4_dists"])
+    assert ids_match_modulo_ties(ids[:32], ds[:32], g["c4_ids"], g["c4_dists"])
+    idx.close()

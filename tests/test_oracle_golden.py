@@ -7,7 +7,7 @@ reference calls libm through a different overload)."""
 import numpy as np
 import pytest
 
-from tests import orc
+from tests import orc, refio
 
 FLOAT_SPACES = ("l2", "l1", "linf", "cosinesimil", "angulardist", "negdotprod")
 RTOL = 1e-5
@@ -112,3 +112,17 @@ def test_hnsw_u8_generic_path_bit_exact(golden):
 def test_level_stream_is_mt19937_seed0(golden):
     lv = orc.random_levels(300, M=8, seed=0)
     np.testing.assert_array_equal(lv, golden["hnsw_l2_levels"])
+
+
+def test_oracle_matches_reference_full_size_fixture_subsample():
+    """golden_v3 (the reference's scan of the 1M-row BASELINE sets, independent queries): the oracle reproduces it on a
+    few queries -- the pin of the full-size GPU tests travels through the same formulas."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_v3.npz"))
+    X, Q = refio.s_lowrank(1_000_000, 128, 42), refio.s_lowrank(1024, 128, 43)
+    pos, d, _ = orc.seq_search("l2", X, Q[:4], 10)
+    np.testing.assert_array_equal(pos, g["c2_ids"][:4])
+    np.testing.assert_array_equal(d, g["c2_dists"][:4])
+    U, UQ = refio.s_sift_like(1_000_000, 44), refio.s_sift_like(4096, 45)
+    pos, d, _ = orc.seq_search("l2sqr_sift", U, UQ[:2], 100)
+    np.testing.assert_array_equal(d, g["c4_dists"][:2])
