@@ -788,15 +788,20 @@ void Engine::finalize() {
             d_auxp_.release();
             const bool fast_space = space_ == SP_L2 || space_ == SP_NEGDOT ||
                                     ((space_ == SP_COSINE || space_ == SP_ANGULAR) && !centred_);
-            if (fast_space && dim_ <= 128 && n >= 65536) {
+            if (fast_space && dim_ <= 1024 && n >= 65536) {
+                // (rows up to 128 dimensions: hi and lo tiles; longer rows, round 3: hi tiles of 128 * kch columns
+                //  for the K-chunked one-product scan -- the plan's kch, which depends on the dimension only)
+                const BfF32Fast f0 = bf_f32_fast_plan((int)n, (int)dim_, 1024, 10, space_, centred_);
+                const size_t dp = f0.use ? (size_t)f0.dp : 128;
                 const size_t n_pad = (size_t)bf_f32_rows_padded((int)n);
-                d_bf_hi_.ensure(n_pad * 128 * 2);
-                d_bf_lo_.ensure(n_pad * 128 * 2);
+                d_bf_hi_.ensure(n_pad * dp * 2);
+                if (dp == 128) d_bf_lo_.ensure(n_pad * 128 * 2);
                 d_auxp_.ensure(n_pad * 4);
                 const float pad = space_ == SP_L2 ? -INFINITY : 0.f;
-                hip_check(launch_split_bf16(sel_rows, (int)n, (int)n_pad, ldb_, (int)dim_, d_bf_hi_.ptr(), d_bf_lo_.ptr(),
+                hip_check(launch_split_bf16(sel_rows, (int)n, (int)n_pad, ldb_, (int)dim_, d_bf_hi_.ptr(),
+                                            dp == 128 ? d_bf_lo_.ptr() : nullptr,
                                             space_ == SP_NEGDOT ? nullptr : d_aux_.as<float>(), pad, d_auxp_.as<float>(),
-                                            stream_),
+                                            stream_, (int)dp),
                           "split rows");
                 have_bf16_ = true;
             }
@@ -1087,7 +1092,7 @@ void Engine::knn_brute(const void* d_queries, size_t nq, size_t k, int32_t* d_id
             }
             ws_cand_.ensure(bf_cand_elems(f.fallback) * 8);
             ws_cnt_.ensure(bf_cnt_elems(f.fallback) * 4);
-            ws_f32_q_.ensure((size_t)f.qpad * 128 * 2 * 2);
+            ws_f32_q_.ensure((size_t)f.qpad * f.dp * 2 * 2);
             ws_u8_cand_.ensure(bf_f32_top8_elems(f) * 4);
             ws_u8_thr_.ensure(bf_f32_thr_bytes(f));
             ws_flags_.ensure((size_t)f.fallback.nqt * 4 + 64);
@@ -1096,7 +1101,7 @@ void Engine::knn_brute(const void* d_queries, size_t nq, size_t k, int32_t* d_id
             float* thr = ws_u8_thr_.as<float>();
             int* tile_fail = reinterpret_cast<int*>(thr + 2 * (size_t)f.qpad);
             char* qh = ws_f32_q_.as<char>();
-            char* ql = qh + (size_t)f.qpad * 128 * 2;
+            char* ql = qh + (size_t)f.qpad * f.dp * 2;
             hipEvent_t eb = nullptr, ee = nullptr;
             if (prof_ && prof_events_.size() < 65536) {
                 hip_check(hipEventCreate(&eb), "hipEventCreate");

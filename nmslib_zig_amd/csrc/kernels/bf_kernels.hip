@@ -1708,7 +1708,10 @@ __global__ __launch_bounds__(256) void bf_scan_f32_kernel(BfScanF32Args a) {
 // ---------------------------------------------------------------------------------------
 // SAMPLE = the sample pass (every tile_stride-th tile; per-lane top-8 of the blocks' best scores instead of lists): the
 // SAME arithmetic as the scan, so a sampled row scores the same bits in both.
-template <int MODE, bool SAMPLE, int QG, int NW>
+// KCH > 1 (round 3): rows longer than 128 -- KCH chunks of 128 dimensions, one stage per (64-row tile, chunk); the two
+// blocks of a tile keep accumulating through the tile's KCH stages and are checked after its last one; the query
+// fragments of all chunks live in AGPRs (32 * KCH per group: QG = 1, NW = 4 -- 128 queries per workgroup).
+template <int MODE, bool SAMPLE, int QG, int NW, int KCH = 1>
 __global__ __launch_bounds__(NW * 64) void bf_scan_bf16_kernel(BfScanF32Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1729,20 +1732,22 @@ __global__ __launch_bounds__(NW * 64) void bf_scan_bf16_kernel(BfScanF32Args a) 
     const int tstr = SAMPLE ? a.tile_stride : 1;
     const int tiles_all = (a.n + BF_BN - 1) / BF_BN;
     const int stiles_all = (tiles_all + tstr - 1) / tstr;
-    const int nstages = max(0, min(a.tps, stiles_all - split * a.tps));
+    const int ntiles = max(0, min(a.tps, stiles_all - split * a.tps));
+    const int nstages = ntiles * KCH;   // one stage per (tile, chunk of 128 dimensions)
+    constexpr int kDp = 128 * KCH;       // row length of the bf16 tiles
     const int r_begin = split * a.tps * tstr * BF_BN;
     const int stage_rows = tstr * BF_BN;
 
     // one stage = 16 DMA pieces of 1 KiB (4 rows x 256 B): wave w issues pieces 4w .. 4w+3 and 16 of the 64 aux values
     auto issue_tile = [&](int stage) __attribute__((always_inline)) {
         const int slot = stage % kRing;
-        const int row0 = r_begin + stage * stage_rows;
+        const int row0 = r_begin + (stage / KCH) * stage_rows;
 #pragma unroll
         for (int jj = 0; jj < 16 / NW; ++jj) {
             const int pj = (16 / NW) * wave + jj;
             const int row = 4 * pj + (lane >> 4);
             const int c = (lane & 15) ^ (row & 15);
-            const __bf16* src = a.base_hi + (size_t)(row0 + row) * 128 + c * 8;
+            const __bf16* src = a.base_hi + (size_t)(row0 + row) * kDp + (stage % KCH) * 128 + c * 8;
             __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(ring + slot * kStageBytes + pj * 1024), 16, 0, 0);
         }
         if (lane < 64 / NW)
@@ -1750,7 +1755,7 @@ __global__ __launch_bounds__(NW * 64) void bf_scan_bf16_kernel(BfScanF32Args a) 
                                              (lptr_t)(auxr + (stage % kAuxRing) * BF_BN + (64 / NW) * wave), 4, 0, 0);
     };
 
-    bf16x8 qh[QG][8];
+    bf16x8 qh[QG][8 * KCH];
     float thr[QG];
     int cnt[QG], ecnt[QG];
     uint32_t* lp[QG];
@@ -1759,8 +1764,8 @@ __global__ __launch_bounds__(NW * 64) void bf_scan_bf16_kernel(BfScanF32Args a) 
     for (int g = 0; g < QG; ++g) {
         const int qidx = (qt * NW + wave) * (32 * QG) + g * 32 + l31;
 #pragma unroll
-        for (int kc = 0; kc < 8; ++kc)
-            asm volatile("global_load_dwordx4 %0, %1, off" : "=a"(qh[g][kc]) : "v"(a.q_hi + (size_t)qidx * 128 + 16 * kc + 8 * h) : "memory");
+        for (int kc = 0; kc < 8 * KCH; ++kc)
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=a"(qh[g][kc]) : "v"(a.q_hi + (size_t)qidx * kDp + 16 * kc + 8 * h) : "memory");
         cnt[g] = 0;
         ecnt[g] = 0;
         if constexpr (SAMPLE) {
@@ -1922,12 +1927,21 @@ __global__ __launch_bounds__(NW * 64) void bf_scan_bf16_kernel(BfScanF32Args a) 
     load_init(aux_a);
     load_frag(ring_a, 0);
     load_frag(ring_a, 1);
-    for (int t = 0; t < nstages; ++t) {
+    for (int tt = 0; tt < ntiles; ++tt) {
+#pragma unroll
+      for (int ch = 0; ch < KCH; ++ch) {
+        const int t = tt * KCH + ch;
+        constexpr bool kOne = KCH == 1;
+        const bool first_ch = kOne || ch == 0, last_ch = kOne || ch == KCH - 1;
         const uint32_t th_ = ring_a + (t % kRing) * kStageBytes;
         const float* axs = auxr + (t % kAuxRing) * BF_BN + 4 * h;
-        const int row0 = r_begin + t * stage_rows;
+        const int row0 = r_begin + tt * stage_rows;
 #pragma unroll
         for (int blk = 0; blk < 2; ++blk) {
+            // the block before this one holds a tile's final scores iff it ran the tile's last chunk; this block
+            // starts from the start values iff it runs the tile's first chunk; the block behind it likewise
+            const bool prev_final = blk == 1 ? last_ch : first_ch;
+            const bool init_next = blk == 0 ? first_ch : last_ch;
             const uint32_t rp = th_ + blk * 32 * 256;
             const uint32_t nrp = blk == 0 ? th_ + 32 * 256 : ring_a + ((t + 1) % kRing) * kStageBytes;
             const uint32_t nax = blk == 0 ? aux_a + ((t % kAuxRing) * BF_BN + 32) * 4 : aux_a + (((t + 1) % kAuxRing) * BF_BN) * 4;
@@ -1937,12 +1951,12 @@ __global__ __launch_bounds__(NW * 64) void bf_scan_bf16_kernel(BfScanF32Args a) 
                 // the next block's start values) stay in flight
                 if (kc + 2 < 8) {
                     load_frag(rp, kc + 2);
-                    wait_frag(std::integral_constant<int, 2>{}, kc, kc == 0 && MODE == SC_L2);
+                    wait_frag(std::integral_constant<int, 2>{}, kc, kc == 0 && MODE == SC_L2 && first_ch);
                 } else {
                     // (also in the very last block: see bf_scan_f32_kernel)
-                    if (kc == 6) load_init(nax);
+                    if (kc == 6 && init_next) load_init(nax);
                     load_frag(nrp, kc + 2 - 8);
-                    if (kInitReads) wait_frag(std::integral_constant<int, 6>{}, kc, false);
+                    if (kInitReads && init_next) wait_frag(std::integral_constant<int, 6>{}, kc, false);
                     else wait_frag(std::integral_constant<int, 2>{}, kc, false);
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -1954,10 +1968,10 @@ __global__ __launch_bounds__(NW * 64) void bf_scan_bf16_kernel(BfScanF32Args a) 
                 // per K-step).
                 constexpr int kEvery = 8 / QG;
                 const int gc = kc / kEvery;
-                const bool chk = (kc % kEvery) == 0, br = (kc % kEvery) == 1;
+                const bool chk = prev_final && (kc % kEvery) == 0, br = prev_final && (kc % kEvery) == 1;
                 float m = 0.f;
                 if (chk) m = block_max(acc[blk ^ 1][gc], pv_ax);   // (also before the first block: no branch between the MFMAs)
-                acc[blk][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[kc % 4], qh[0][kc], kc == 0 ? iv : acc[blk][0], 0, 0, 0);
+                acc[blk][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[kc % 4], qh[0][8 * ch + kc], (kc == 0 && first_ch) ? iv : acc[blk][0], 0, 0, 0);
                 if (br) {
                     __builtin_amdgcn_sched_barrier(0);
                     finish_check(trig_pend, m_pend, acc[blk ^ 1][gc], gc, pv_ax, pv_row0);
@@ -1968,7 +1982,7 @@ __global__ __launch_bounds__(NW * 64) void bf_scan_bf16_kernel(BfScanF32Args a) 
                 }
 #pragma unroll
                 for (int g = 1; g < QG; ++g) {
-                    acc[blk][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[kc % 4], qh[g][kc], kc == 0 ? iv : acc[blk][g], 0, 0, 0);
+                    acc[blk][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[kc % 4], qh[g][8 * ch + kc], (kc == 0 && first_ch) ? iv : acc[blk][g], 0, 0, 0);
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                     __builtin_amdgcn_sched_group_barrier(0x002, 12 / QG, 0);
                 }
@@ -1984,9 +1998,11 @@ __global__ __launch_bounds__(NW * 64) void bf_scan_bf16_kernel(BfScanF32Args a) 
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            pv_ax = axs + blk * 32;
-            pv_row0 = row0 + blk * 32;
-            have_pv = true;
+            if (last_ch) {
+                pv_ax = axs + blk * 32;
+                pv_row0 = row0 + blk * 32;
+                have_pv = true;
+            }
             if (blk == 0) {
                 // every kSync stages: the next kSync stages (requested at the last meeting) must have landed; behind the
                 // barrier no wave reads the kSync stages before this one any more: their slots take the next requests
@@ -1996,6 +2012,7 @@ __global__ __launch_bounds__(NW * 64) void bf_scan_bf16_kernel(BfScanF32Args a) 
                 }
             }
         }
+      }
     }
     // (the prefetches the last block issued for a block that does not exist: their registers are free only now)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -2022,15 +2039,15 @@ __global__ __launch_bounds__(NW * 64) void bf_scan_bf16_kernel(BfScanF32Args a) 
 // rows -> two bf16 tiles (hi = bf16(x), lo = bf16(x - hi)), padded to 128 columns and n_pad rows; auxp = aux with the
 // pad rows' value
 __global__ void split_bf16_kernel(const float* src, int rows, int rows_pad, int ld, int dim, __bf16* hi, __bf16* lo,
-                                  const float* aux, float aux_pad, float* auxp) {
-    const size_t total = (size_t)rows_pad * 128;
+                                  const float* aux, float aux_pad, float* auxp, int dp) {
+    const size_t total = (size_t)rows_pad * dp;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const size_t r = i >> 7;
-        const int c = (int)(i & 127);
+        const size_t r = i / (size_t)dp;
+        const int c = (int)(i - r * dp);
         const float v = (r < (size_t)rows && c < dim) ? src[r * ld + c] : 0.f;
         const __bf16 hh = (__bf16)v;
         hi[i] = hh;
-        lo[i] = (__bf16)(v - (float)hh);
+        if (lo) lo[i] = (__bf16)(v - (float)hh);
         if (c == 0 && auxp) auxp[r] = r < (size_t)rows ? (aux ? aux[r] : 0.f) : aux_pad;
     }
 }
@@ -2041,12 +2058,13 @@ __global__ void split_bf16_kernel(const float* src, int rows, int rows_pad, int 
 //   and the words every later kernel of the batch expects to find cleared: the fast path's tile flags, the verified
 //   adaptive path's flags, both shared-threshold regions of the fallback selections.
 __global__ void bf_f32_prep_kernel(const float* raw, int nq, int dim, const float* sel, int qpad, int ld, float* pad_out,
-                                   __bf16* hi, __bf16* lo, int* clr0, int n0, int* clr1, int n1, uint32_t* clr2, size_t n2) {
+                                   __bf16* hi, __bf16* lo, int* clr0, int n0, int* clr1, int n1, uint32_t* clr2, size_t n2,
+                                   int dp) {
     const size_t gtid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, gsz = (size_t)gridDim.x * blockDim.x;
-    const size_t total = (size_t)qpad * 128;
+    const size_t total = (size_t)qpad * dp;
     for (size_t i = gtid; i < total; i += gsz) {
-        const size_t r = i >> 7;
-        const int c = (int)(i & 127);
+        const size_t r = i / (size_t)dp;
+        const int c = (int)(i - r * dp);
         float v;
         if (raw) {
             v = (r < (size_t)nq && c < dim) ? raw[r * dim + c] : 0.f;
@@ -2056,7 +2074,7 @@ __global__ void bf_f32_prep_kernel(const float* raw, int nq, int dim, const floa
         }
         const __bf16 hh = (__bf16)v;
         hi[i] = hh;
-        lo[i] = (__bf16)(v - (float)hh);
+        if (lo) lo[i] = (__bf16)(v - (float)hh);
     }
     for (size_t i = gtid; i < (size_t)n0; i += gsz) clr0[i] = 0;
     for (size_t i = gtid; i < (size_t)n1; i += gsz) clr1[i] = 0;
@@ -2159,6 +2177,7 @@ struct RerankListF32Args {
     const float* thr;          // [qpad] thresholds of the split-product scan (score units)
     const float* thr1;         // [qpad] thresholds of the one-product scan
     const int* precise;        // [query tiles] which scan served the tile (1: split product)
+    int no_split;              // rows longer than 128: no split-product scan -- a `precise` tile goes to the adaptive kernel
     float bmax;                // largest row norm of the selection rows
     float bres;                // largest bf16 rounding residual of the selection rows (see row_maxnorm_kernel)
 };
@@ -2204,6 +2223,10 @@ __global__ __launch_bounds__(256) void bf_rerank_f32_list_kernel(RerankListF32Ar
     }
     __syncthreads();
     const int total = offs[nl];
+    if (a.no_split && a.precise[q / a.fail_queries] != 0) {   // (no scan served this tile: its lists are stale)
+        if (tid == 0) atomicOr(&a.tile_fail[q / a.fail_queries], 1);
+        return;
+    }
     const int need = a.k < a.n ? a.k : a.n;
     // the adaptive kernel keeps k' = k + max(4, k/8) per split: ask for the same slack over the whole base here
     const int want = need + (a.k / 8 > 4 ? a.k / 8 : 4) < a.n ? need + (a.k / 8 > 4 ? a.k / 8 : 4) : a.n;
@@ -2221,60 +2244,72 @@ __global__ __launch_bounds__(256) void bf_rerank_f32_list_kernel(RerankListF32Ar
     // the order of its xor-32 and xor-16 steps, and the xor 8 / 4 / 2 / 1 steps run across the 16 lanes.
     const float* qq = a.queries + (size_t)q * a.ldb;
     const int sub = lane & 15, rg = lane >> 4;
-    float qv[8];
-    bool ok[8];
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-        const int d = sub + 16 * c;          // c = 0..3: dimension of virtual lane sub + 16c; c = 4..7: the same + 64
-        ok[c] = d < a.dim;
-        qv[c] = ok[c] ? qq[d] : 0.f;
-    }
+    // lane `sub` of a row's 16 lanes plays the virtual lanes v = sub, sub + 16, sub + 32, sub + 48 of
+    // wave_exact_distance_f32: virtual lane v runs ONE fma chain over the dimensions v, v + 64, v + 128, ... (any row
+    // length since round 3: two 64-dimension steps per pass, the chains carried across the passes)
+    const int nstep = (a.dim + 63) >> 6;
     for (int j0 = wave * 16; j0 < total; j0 += 64) {
         uint32_t pos[4];
-        float xv[4][8];
+        const float* rowp[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int j = j0 + 4 * u + rg;
             pos[u] = (uint32_t)keys[j < total ? j : total - 1];
-            const float* row = a.base + (size_t)pos[u] * a.ldb + sub;
-#pragma unroll
-            for (int c = 0; c < 8; ++c) xv[u][c] = ok[c] ? row[16 * c] : 0.f;
+            rowp[u] = a.base + (size_t)pos[u] * a.ldb + sub;
         }
-        __builtin_amdgcn_wave_barrier();
+        float p0[4][4], p1[4][4], p2[4][4];   // [row][virtual lane]
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            float p0[4], p1[4], p2[4];   // per virtual lane: the fma chain over dimensions v, v + 64
+        for (int u = 0; u < 4; ++u)
 #pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                p0[v] = p1[v] = p2[v] = 0.f;
+            for (int v = 0; v < 4; ++v) p0[u][v] = p1[u][v] = p2[u][v] = 0.f;
+        for (int c0 = 0; c0 < nstep; c0 += 2) {
+            float xv[4][8], qv[8];
+            bool ok[8];
 #pragma unroll
-                for (int c = 0; c < 2; ++c) {
-                    if (64 * c >= a.dim) continue;    // (wave_exact_distance_f32 stops at the last 64-chunk)
-                    const float x = xv[u][v + 4 * c], y = qv[v + 4 * c];
-                    if (a.space == SP_L2) {
-                        const float t = x - y;
-                        p0[v] = fmaf(t, t, p0[v]);
-                    } else {
-                        p0[v] = fmaf(x, y, p0[v]);
-                        if (a.space != SP_NEGDOT) {
-                            p1[v] = fmaf(x, x, p1[v]);
-                            p2[v] = fmaf(y, y, p2[v]);
+            for (int c = 0; c < 8; ++c) {
+                const int d = sub + 16 * (c & 3) + 64 * (c0 + (c >> 2));   // c = 0..3: step c0, c = 4..7: step c0 + 1
+                ok[c] = d < a.dim;
+                qv[c] = ok[c] ? qq[d] : 0.f;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) xv[u][c] = ok[c] ? rowp[u][16 * (c & 3) + 64 * (c0 + (c >> 2))] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) {
+                        if (64 * (c0 + c) >= a.dim) continue;    // (wave_exact_distance_f32 stops at the last 64-chunk)
+                        const float x = xv[u][v + 4 * c], y = qv[v + 4 * c];
+                        if (a.space == SP_L2) {
+                            const float t = x - y;
+                            p0[u][v] = fmaf(t, t, p0[u][v]);
+                        } else {
+                            p0[u][v] = fmaf(x, y, p0[u][v]);
+                            if (a.space != SP_NEGDOT) {
+                                p1[u][v] = fmaf(x, x, p1[u][v]);
+                                p2[u][v] = fmaf(y, y, p2[u][v]);
+                            }
                         }
                     }
                 }
             }
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
             auto tree = [&](const float* p) __attribute__((always_inline)) -> float {
                 float s = (p[0] + p[2]) + (p[1] + p[3]);     // xor 32, then xor 16
 #pragma unroll
                 for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
                 return s;
             };
-            const float s0 = tree(p0);
+            const float s0 = tree(p0[u]);
             float d;
             if (a.space == SP_L2) d = sqrtf(s0);
             else if (a.space == SP_NEGDOT) d = -s0;
             else {
-                const float sim = normdot_finish(s0, tree(p1), tree(p2));
+                const float sim = normdot_finish(s0, tree(p1[u]), tree(p2[u]));
                 d = a.space == SP_ANGULAR ? acosf(sim) : fmaxf(0.0f, 1.0f - sim);
             }
             const int j = j0 + 4 * u + rg;
@@ -3231,15 +3266,20 @@ hipError_t launch_bf_u8_fast(const BfU8Fast& f, int n, int nq, int k, const uint
 BfF32Fast bf_f32_fast_plan(int n, int dim, int nq, int k, int space, bool cosine_centred) {
     BfF32Fast f{};
     const bool space_ok = space == SP_L2 || space == SP_NEGDOT || ((space == SP_COSINE || space == SP_ANGULAR) && !cosine_centred);
-    f.use = space_ok && dim <= 128 && n >= 65536 && nq >= 256 && k <= 128;
+    f.use = space_ok && dim <= 1024 && n >= 65536 && nq >= 256 && k <= 128;
     if (const char* e = getenv("NMSLIB_GPU_F32_FAST")) f.use = f.use && atoi(e) != 0;
     if (!f.use) return f;
     f.mode = space == SP_L2 ? 0 : (space == SP_NEGDOT ? 1 : 2);
+    // rows longer than 128 (round 3): chunks of 128 dimensions (bf_scan_bf16_kernel<.., KCH>), instantiated for 2, 3, 4, 6, 8
+    f.kch = dim <= 128 ? 1 : (dim <= 256 ? 2 : (dim <= 384 ? 3 : (dim <= 512 ? 4 : (dim <= 768 ? 6 : 8))));
+    f.dp = 128 * f.kch;
     // queries per workgroup = 256 * qg: four waves x (2 or 4) groups of 32 (see bf_scan_f32_kernel); the larger shape
     // halves the L2 -> LDS stream and the LDS reads per MFMA once the batch fills the chip with it
     f.qg = nq >= 1024 ? 2 : 1;
     if (const char* e = getenv("NMSLIB_GPU_F32_QG")) f.qg = atoi(e) == 2 ? 2 : (atoi(e) == 1 ? 1 : f.qg);
-    const int tq = 256 * f.qg;
+    if (f.kch > 1) f.qg = 1;   // (the fragments of all chunks fill the AGPRs: one group of 32 queries per wave, four waves)
+    const int tq = f.kch > 1 ? 128 : 256 * f.qg;
+    f.tq = tq;
     f.qpad = (nq + tq - 1) / tq * tq;
     f.nqt = f.qpad / tq;
     f.stride = 16;  // (measured at C2 with the one-product sample pass, ms/step: 4 -> 0.457, 8 -> 0.427, 16 -> 0.419)
@@ -3272,7 +3312,7 @@ BfF32Fast bf_f32_fast_plan(int n, int dim, int nq, int k, int space, bool cosine
     f.lds_scan1 = 9 * BF_BN * 256 + 16 * BF_BN * 4 + 64;
     f.lds_rerank = (size_t)f.p2max * 8 + (2 * (size_t)ns + 1) * 4 + 16;
     const int stiles = (tiles_all + f.stride - 1) / f.stride;
-    const int s_nqt = f.qpad / 256;
+    const int s_nqt = f.qpad / (f.kch > 1 ? 128 : 256);
     int nss = (256 + s_nqt - 1) / s_nqt;
     if (nss > stiles / 16) nss = stiles / 16;
     if (nss > 64) nss = 64;
@@ -3282,6 +3322,7 @@ BfF32Fast bf_f32_fast_plan(int n, int dim, int nq, int k, int space, bool cosine
     f.s_tps = (stiles + nss - 1) / nss;
     f.lds_thr = (size_t)host_next_pow2(nss * 2 * 8) * 8 + 16;
     f.fallback = bf_make_plan(n, dim, nq, k, false, tq);
+    if (f.kch > 1) f.force_precise = false;   // (no split-product scan at these lengths: such tiles go to the adaptive kernel)
     return f;
 }
 
@@ -3296,13 +3337,13 @@ hipError_t launch_row_maxnorm(const float* rows, int n, int ld, int dim, bool re
 }
 
 hipError_t launch_split_bf16(const float* src, int rows, int rows_pad, int ld, int dim, void* hi, void* lo,
-                             const float* aux, float aux_pad, float* auxp, hipStream_t s) {
-    const size_t total = (size_t)rows_pad * 128;
+                             const float* aux, float aux_pad, float* auxp, hipStream_t s, int dp) {
+    const size_t total = (size_t)rows_pad * dp;
     if (total == 0) return hipSuccess;
     size_t grid = (total + 255) / 256;
     if (grid > 16384) grid = 16384;
     hipLaunchKernelGGL(split_bf16_kernel, dim3((unsigned)grid), dim3(256), 0, s, src, rows, rows_pad, ld, dim,
-                       static_cast<__bf16*>(hi), static_cast<__bf16*>(lo), aux, aux_pad, auxp);
+                       static_cast<__bf16*>(hi), static_cast<__bf16*>(lo), aux, aux_pad, auxp, dp);
     return hipGetLastError();
 }
 
@@ -3324,13 +3365,30 @@ static hipError_t launch_scan_bf16_one(const BfScanF32Args& a, int grid, size_t 
 }
 // terms: 3 = the split product, 1 = one bf16 product (the sample pass: always, 256 queries per workgroup)
 template <int MODE>
-static hipError_t launch_scan_f32_mode(const BfScanF32Args& a, bool sample, int terms, int qg, int grid, size_t lds, hipStream_t s) {
+static hipError_t launch_scan_f32_mode(const BfScanF32Args& a, bool sample, int terms, int qg, int grid, size_t lds, hipStream_t s, int kch = 1) {
     // The one-product kernel runs with EIGHT waves per workgroup, two per SIMD, each serving half the query groups of the
     // four-wave shape (same workgroup, same tile stream): its K-step is short (two MFMAs), and what one wave cannot hide at
     // one wave per SIMD -- a branch, a VALU chain in front of it, the start-value copy -- the other wave's MFMAs cover.
     // Measured at C2, same box: scan 0.2675 -> 0.2545 ms, sample pass too (step 0.400 -> 0.3925 ms); 512-query batches:
     // scan 0.169 -> 0.155 ms.  NMSLIB_GPU_BF16_W8 (bits: 1 = 512-query tiles, 2 = 256-query tiles, 4 = sample pass) selects
     // the shape for experiments; the split-product kernel needs the whole register file of a SIMD and stays at four waves.
+    if (kch > 1) {   // rows longer than 128: four waves x one group of 32 queries, the chunks' fragments in AGPRs
+        if (terms != 1) return hipSuccess;   // (no split-product scan at these lengths)
+        auto go = [&](auto kern) -> hipError_t {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, a);
+            return hipGetLastError();
+        };
+        switch (kch) {
+            case 2: return sample ? go(bf_scan_bf16_kernel<MODE, true, 1, 4, 2>) : go(bf_scan_bf16_kernel<MODE, false, 1, 4, 2>);
+            case 3: return sample ? go(bf_scan_bf16_kernel<MODE, true, 1, 4, 3>) : go(bf_scan_bf16_kernel<MODE, false, 1, 4, 3>);
+            case 4: return sample ? go(bf_scan_bf16_kernel<MODE, true, 1, 4, 4>) : go(bf_scan_bf16_kernel<MODE, false, 1, 4, 4>);
+            case 6: return sample ? go(bf_scan_bf16_kernel<MODE, true, 1, 4, 6>) : go(bf_scan_bf16_kernel<MODE, false, 1, 4, 6>);
+            case 8: return sample ? go(bf_scan_bf16_kernel<MODE, true, 1, 4, 8>) : go(bf_scan_bf16_kernel<MODE, false, 1, 4, 8>);
+            default: return hipErrorInvalidValue;
+        }
+    }
     const char* w8e = getenv("NMSLIB_GPU_BF16_W8");
     const int w8 = w8e ? atoi(w8e) : 7;
     if (sample) return (w8 & 4) ? launch_scan_bf16_one<MODE, true, 1, 8>(a, grid, lds, s) : launch_scan_bf16_one<MODE, true, 2, 4>(a, grid, lds, s);
@@ -3356,20 +3414,20 @@ hipError_t launch_bf_f32_fast(const BfF32Fast& f, int space, int n, int dim, int
         const BfPlan& fb = f.fallback;
         uint32_t* gthr = reinterpret_cast<uint32_t*>(cnt_fb + (size_t)fb.qpad * fb.nsplit);
         const size_t gwords = 2 * ((size_t)fb.qpad + (size_t)fb.qpad * fb.nsplit);
-        size_t work = (size_t)f.qpad * 128 > gwords ? (size_t)f.qpad * 128 : gwords;
+        size_t work = (size_t)f.qpad * f.dp > gwords ? (size_t)f.qpad * f.dp : gwords;
         size_t grid = (work + 255) / 256;
         if (grid > 2048) grid = 2048;
         hipLaunchKernelGGL(bf_f32_prep_kernel, dim3((unsigned)grid), dim3(256), 0, s, queries_raw, nq, dim, queries_sel, f.qpad,
-                           ldb, queries_pad_out, static_cast<__bf16*>(q_hi), static_cast<__bf16*>(q_lo), tile_fail, 2 * f.nqt,
-                           flags_fb, fb.nqt, gthr, gwords);
+                           ldb, queries_pad_out, static_cast<__bf16*>(q_hi), f.kch > 1 ? nullptr : static_cast<__bf16*>(q_lo),
+                           tile_fail, 2 * f.nqt, flags_fb, fb.nqt, gthr, gwords, f.dp);
         e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
     auto scan = [&](const BfScanF32Args& sa, bool sample, int terms, int grid) -> hipError_t {
         const size_t lds = terms == 1 ? f.lds_scan1 : f.lds_scan;
-        if (f.mode == 0) return launch_scan_f32_mode<SC_L2>(sa, sample, terms, f.qg, grid, lds, s);
-        if (f.mode == 1) return launch_scan_f32_mode<SC_DOT>(sa, sample, terms, f.qg, grid, lds, s);
-        return launch_scan_f32_mode<SC_COS>(sa, sample, terms, f.qg, grid, lds, s);
+        if (f.mode == 0) return launch_scan_f32_mode<SC_L2>(sa, sample, terms, f.qg, grid, lds, s, f.kch);
+        if (f.mode == 1) return launch_scan_f32_mode<SC_DOT>(sa, sample, terms, f.qg, grid, lds, s, f.kch);
+        return launch_scan_f32_mode<SC_COS>(sa, sample, terms, f.qg, grid, lds, s, f.kch);
     };
     BfScanF32Args a{};
     a.base_hi = static_cast<const __bf16*>(base_hi);
@@ -3381,7 +3439,7 @@ hipError_t launch_bf_f32_fast(const BfF32Fast& f, int space, int n, int dim, int
     a.nqt = f.nqt;
     // 1. sample pass (one product: the scores carry the error E1) + thresholds + the choice of the scan per query tile
     BfScanF32Args sa = a;
-    sa.nqt = f.qpad / 256;
+    sa.nqt = f.qpad / (f.kch > 1 ? 128 : 256);
     sa.nsplit = f.s_nsplit;
     sa.tps = f.s_tps;
     sa.tile_stride = f.stride;
@@ -3394,7 +3452,7 @@ hipError_t launch_bf_f32_fast(const BfF32Fast& f, int space, int n, int dim, int
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(bf_f32_threshold_kernel, dim3(f.qpad), dim3(256), f.lds_thr, s, top8, 2 * f.s_nsplit,
                        f.rcap <= 64 && f.s_nsplit >= 32 ? 4 : 8, f.r, f.rcap, nq,
-                       queries_sel, ldb, dim, f.mode == 2 ? 1.0f : bmax, bres, 256 * f.qg, f.force_precise ? 1 : 0, thr,
+                       queries_sel, ldb, dim, f.mode == 2 ? 1.0f : bmax, bres, f.tq, f.force_precise ? 1 : 0, thr,
                        thr1, precise);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
@@ -3436,7 +3494,8 @@ hipError_t launch_bf_f32_fast(const BfF32Fast& f, int space, int n, int dim, int
     r.caph = f.caph;
     r.tps = f.tps;
     r.p2max = f.p2max;
-    r.fail_queries = 256 * f.qg;
+    r.fail_queries = f.tq;
+    r.no_split = f.kch > 1 ? 1 : 0;
     r.space = space;
     r.dim = dim;
     r.ldb = ldb;
@@ -3486,7 +3545,7 @@ hipError_t launch_bf_f32_fast(const BfF32Fast& f, int space, int n, int dim, int
     // 4. fallback: the adaptive f32 kernel + its re-rank (verified for l2, with its exact tail) for flagged query tiles
     //    (256 * qg queries = 2 * qg of its tiles)
     return launch_bf_adaptive_f32(f.fallback, space, dim, k, base_orig, sel_rows, aux, queries_orig, queries_sel, nullptr, bmax,
-                                  cand_fb, cnt_fb, flags_fb, ext_ids, out_ids, out_dists, out_cnt, tile_fail, 2 * f.qg, s,
+                                  cand_fb, cnt_fb, flags_fb, ext_ids, out_ids, out_dists, out_cnt, tile_fail, f.tq / 128, s,
                                   /*cleared=*/true);
 }
 

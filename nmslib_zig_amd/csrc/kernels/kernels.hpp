@@ -123,7 +123,10 @@ struct BfF32Fast {
     bool use;
     int mode;                  // 0 l2, 1 negdotprod, 2 cosine / angular (uncentred)
     int qg;                    // a scan workgroup serves 256 * qg queries (= one query tile)
-    int qpad, nqt;             // queries padded to 256 * qg; scan query tiles
+    int kch;                   // rows longer than 128: chunks of 128 dimensions per row (1 = the classic shape)
+    int dp;                    // 128 * kch: row length of the bf16 tiles
+    int tq;                    // queries per scan workgroup / query tile: 256 * qg, or 128 when kch > 1
+    int qpad, nqt;             // queries padded to tq; scan query tiles
     int stride, r;
     int rcap;                  // one-product scan: its threshold may sit as low as the rcap-th best sample score
     bool force_precise;        // NMSLIB_GPU_F32_TERMS=3: every tile through the split-product scan
@@ -144,7 +147,7 @@ inline int bf_f32_rows_padded(int n) { return (n + BF_BN - 1) / BF_BN * BF_BN + 
 // largest row norm -> *out (device float)
 hipError_t launch_row_maxnorm(const float* rows, int n, int ld, int dim, bool relative_residual, float* out, hipStream_t s);
 hipError_t launch_split_bf16(const float* src, int rows, int rows_pad, int ld, int dim, void* hi, void* lo,
-                             const float* aux, float aux_pad, float* auxp, hipStream_t s);
+                             const float* aux, float aux_pad, float* auxp, hipStream_t s, int dp = 128);
 hipError_t launch_bf_f32_fast(const BfF32Fast& f, int space, int n, int dim, int ldb, int nq, int k, const float* base_orig,
                               const float* sel_rows, const float* aux, const void* base_hi, const void* base_lo,
                               const float* auxp, float bmax, float bres, const float* queries_orig, const float* queries_sel,

@@ -676,3 +676,33 @@ def test_full_size_c4_independent_queries_equal_the_reference():
     np.testing.assert_array_equal(ds[:32], g["c4_dists"])
     assert ids_match_modulo_ties(ids[:32], ds[:32], g["c4_ids"], g["c4_dists"])
     idx.close()
+
+
+@pytest.mark.parametrize("space,D", [("l2", 768), ("cosinesimil", 768), ("negdotprod", 200), ("l2", 300), ("angulardist", 512),
+                                     ("l2", 1000)])
+def test_f32_fast_path_long_rows(space, D, monkeypatch):
+    """Rows longer than 128 (round 3): the one-product scan in chunks of 128 dimensions (bf_scan_bf16_kernel<.., KCH>),
+    same sample / threshold / list re-rank / proof chain.  66k rows x D, 300 queries: the fast path runs (path 1), the
+    answers are the oracle's, and they are the adaptive f32-MFMA path's bit for bit (both end in the reference formula
+    on the original rows, lane for lane)."""
+    n, nq, k = 66000, 300, 10
+    X, Q = refio.s_lowrank(n, D, 301), refio.s_lowrank(nq, D, 302)
+    idx = make_index(space, "seq_search", X)
+    ids, ds, cnt = idx.knnQueryBatch(Q, k)
+    st = idx.stats()
+    assert st["last_path"] == 1, st
+    assert st["fast_tiles_fallback"] <= 1, st
+    monkeypatch.setenv("NMSLIB_GPU_F32_FAST", "0")
+    ids0, ds0, _ = idx.knnQueryBatch(Q, k)
+    assert idx.stats()["last_path"] == 0
+    monkeypatch.delenv("NMSLIB_GPU_F32_FAST")
+    np.testing.assert_array_equal(ids, ids0)
+    np.testing.assert_array_equal(ds.view(np.uint32), ds0.view(np.uint32))
+    sel = np.r_[0:12, nq - 12:nq]
+    opos, odist, _ = orc.seq_search(space, X, Q[sel], k + 22)
+    assert refio.recall_nmslib(ids[sel], opos, odist, k) >= 0.999
+    assert close_rel(ds[sel], odist[:, :k], rtol=1e-5, atol=1e-6)
+    for _ in range(5):                                  # race screen at this shape too
+        r = idx.knnQueryBatch(Q, k)
+        np.testing.assert_array_equal(r[0], ids)
+    idx.close()

@@ -20,6 +20,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--n", type=int, default=1_000_000)
     ap.add_argument("--nq", type=int, default=1024)
+    ap.add_argument("--only", default="", help="comma-separated data set names")
     a = ap.parse_args()
     rng = np.random.default_rng(7)
     datasets = {
@@ -28,7 +29,11 @@ def main():
         "gauss32": lambda n: refio.s_gauss(n, 32, 13),
         "siftlike128f": lambda n: refio.s_sift_like(n, 14).astype(np.float32),
         "offset128": lambda n: (refio.s_gauss(n, 128, 15) + np.float32(30.0)),
+        "lowrank768": lambda n: refio.s_lowrank(n, 768, 16),
+        "gauss256": lambda n: refio.s_gauss(n, 256, 17),
     }
+    if a.only:
+        datasets = {k: v for k, v in datasets.items() if k in a.only.split(",")}
     for dname, gen in datasets.items():
         X = gen(a.n)
         Q = gen(a.nq + 7)[7:]
