@@ -238,7 +238,7 @@ def run_workload(a, name, cx):
     import torch
     import torch.distributed as dist
     import nmslib_zig_amd as nz
-    from tests import refio
+    from nmslib_zig_amd import datasets as refio   # synthetic sets + NMSLIB's recall (no test package in the timed path)
 
     w = dict(WORKLOADS[name])
     single = a.workload != "all"

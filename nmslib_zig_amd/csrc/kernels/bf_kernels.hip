@@ -23,7 +23,7 @@
 #include <vector>
 #include <cstdlib>
 
-#include "common.cuh"
+#include "common_dev.hpp"
 #include "kernels.hpp"
 
 namespace gfxknn {
@@ -3132,6 +3132,7 @@ BfU8Fast bf_u8_fast_plan(int n, int nq, int k) {
     f.qpad = (nq + tq - 1) / tq * tq;
     f.nqt = f.qpad / tq;
     f.stride = 8;
+    if (const char* e = getenv("NMSLIB_GPU_U8_STRIDE")) f.stride = atoi(e) > 0 ? atoi(e) : 8;   // (experiments)
     // r-th best of a 1/stride sample: expected k/stride rows of the true top-k fall into the sample; r sits
     // ~3 sigma above that (+ slack), so that fewer than k rows reaching the threshold is a ~1e-6 event per query
     const double kf = (double)k / f.stride;

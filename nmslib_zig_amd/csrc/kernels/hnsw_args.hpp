@@ -1,6 +1,6 @@
 // Kernel arguments shared by the HNSW search kernels (hnsw_kernels.hip, hnsw_mw_kernels.hip).
 #pragma once
-#include "common.cuh"
+#include "common_dev.hpp"
 #include "kernels.hpp"
 
 namespace gfxknn {

@@ -19,7 +19,7 @@
 
 #include <rocprim/device/device_radix_sort.hpp>
 
-#include "hnsw_common.cuh"
+#include "hnsw_common_dev.hpp"
 #include "kernels.hpp"
 
 namespace gfxknn {

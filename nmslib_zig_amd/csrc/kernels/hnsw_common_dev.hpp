@@ -1,6 +1,6 @@
 // Device helpers shared by the HNSW search and construction kernels (wave64).
 #pragma once
-#include "common.cuh"
+#include "common_dev.hpp"
 
 namespace gfxknn {
 

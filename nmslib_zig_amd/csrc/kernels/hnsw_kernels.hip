@@ -17,8 +17,8 @@
 #include <cstdio>
 #include <cstdlib>
 
-#include "hnsw_args.cuh"
-#include "hnsw_common.cuh"
+#include "hnsw_args.hpp"
+#include "hnsw_common_dev.hpp"
 #include "kernels.hpp"
 
 namespace gfxknn {

@@ -9,7 +9,7 @@
 
 #include <rocprim/device/device_radix_sort.hpp>
 
-#include "common.cuh"
+#include "common_dev.hpp"
 #include "kernels.hpp"
 
 namespace gfxknn {

@@ -12,7 +12,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 DOMINANT = ("bf_scan_bf16_kernel", "bf_scan_f32_kernel<0, false", "bf_scan_f32_kernel<1, false", "bf_scan_f32_kernel<2, false",
-            "bf_scan_u8_kernel<4, false", "bf_scan_u8_kernel<2, false", "hnsw_search_kernel")
+            "bf_scan_u8_kernel<4, false", "bf_scan_u8_kernel<2, false", "hnsw_search_mw_kernel", "hnsw_search_kernel")
 
 
 def main():
@@ -29,7 +29,8 @@ def main():
     for w in args:
         shutil.copy(os.path.join(src, f"{tag}_{w}_stats.json"), os.path.join(dst, f"{rnd}_{w}_kernel_stats.json"))
         shutil.copy(os.path.join(src, f"{tag}_{w}_pmc.json"), os.path.join(dst, f"{rnd}_{w}_pmc.json"))
-        for f in glob.glob(os.path.join(src, f"{tag}_{w}_trace", "**", "*kernel_stats.csv"), recursive=True):
+        f = os.path.join(src, f"{tag}_{w}_rocprofv3_kernel_stats.csv")
+        if os.path.exists(f):
             shutil.copy(f, os.path.join(dst, f"{rnd}_{w}_rocprofv3_kernel_stats.csv"))
         pmc = json.load(open(os.path.join(src, f"{tag}_{w}_pmc.json")))
         best = None   # the dominant kernel's most frequent launch shape = the timed batches of bench.py

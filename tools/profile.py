@@ -13,6 +13,7 @@ import csv
 import glob
 import json
 import os
+import shutil
 import subprocess
 import sys
 
@@ -82,6 +83,10 @@ def main():
         e["median_us"] = round(sorted(d)[len(d) // 2], 2)
     stats["per_kernel"] = dict(sorted(per_kernel.items(), key=lambda kv: -kv[1]["total_us"]))
     json.dump(stats, open(os.path.join(out, f"{tag}_{workload}_stats.json"), "w"), indent=1)
+    # keep rocprofv3's own summary, drop the raw traces (gpurun copies back at most 64 MiB)
+    for f in glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True):
+        shutil.copy(f, os.path.join(out, f"{tag}_{workload}_rocprofv3_kernel_stats.csv"))
+    shutil.rmtree(d, ignore_errors=True)
 
     # ---- counter passes ----
     pmc = {}
@@ -101,6 +106,7 @@ def main():
         for k, cs in agg.items():
             for c, (tot, n) in cs.items():
                 pmc.setdefault(k, {})[c] = {"per_dispatch": tot / max(1, n), "dispatches": n}
+        shutil.rmtree(d, ignore_errors=True)
         if rc != 0:
             pmc.setdefault("_errors", {})[name] = log[-2000:]
     json.dump(pmc, open(os.path.join(out, f"{tag}_{workload}_pmc.json"), "w"), indent=1)
@@ -108,8 +114,10 @@ def main():
     for k, e in list(stats["per_kernel"].items())[:6]:
         print(f"{e['timed_avg_us']:>10.1f} us (timed avg) x{e['calls']:<4d} vgpr={e['vgpr']}  {k[:100]}")
     for k, cs in pmc.items():
-        if "select" in k or "hnsw_search" in k:
-            print(k[:80], {c: round(v["per_dispatch"], 1) for c, v in cs.items()})
+        if ("hnsw_search" in k or "bf_scan" in k) and cs.get("SQ_WAVES", {}).get("dispatches", 0) >= 15:
+            print(k[:90], {c: round(v["per_dispatch"], 1) for c, v in cs.items() if c in
+                           ("SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_ANY",
+                            "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_MFMA", "FETCH_SIZE", "WRITE_SIZE", "GRBM_GUI_ACTIVE")})
 
 
 if __name__ == "__main__":
