@@ -1182,10 +1182,35 @@ void Engine::knn_hnsw(const void* d_queries, size_t nq, size_t k, int32_t* d_ids
         knn_hnsw_old(d_queries, nq, k, d_ids, d_dists, d_cnt, stream);
         return;
     }
-    if (std::max<size_t>(ef, k) > 1024)
-        throw EngineError(Err::QueryTooLarge,
-                          "SearchV1Merge with max(ef, k) > 1024 is not supported by the GPU kernel "
-                          "(algoType=old / hybrid with ef >= 1000 has no limit)");
+    if (std::max<size_t>(ef, k) > 1024) {
+        // beyond the LDS kernels' sorted array: the same algorithm with the array in HBM (slices of bounded workspace)
+        int32_t* cnt2 = d_cnt;
+        if (!cnt2) {
+            ws_outcnt_.ensure(nq * 4);
+            cnt2 = ws_outcnt_.as<int32_t>();
+        }
+        const size_t cap = std::max<size_t>(ef, k), words = (d_n_ + 31) / 32;
+        const size_t per_q = cap * 8 + words * 4;
+        const size_t slice = std::max<size_t>(1, std::min<size_t>(nq, ((size_t)4 << 30) / per_q));
+        const size_t qbytes = dim_ * elem_bytes();
+        have_counters_ = true;
+        for (size_t q0 = 0; q0 < nq; q0 += slice) {
+            const size_t m = std::min(slice, nq - q0);
+            ws_old_a_.ensure(m * cap * 4);
+            ws_old_r_.ensure(m * cap * 4);
+            ws_bitset_.ensure(m * words * 4);
+            hip_check(hipMemsetAsync(ws_bitset_.ptr(), 0, m * words * 4, stream), "clear visited bitset");
+            if (q0 == 0) prof_begin(stream);
+            hip_check(launch_hnsw_search_big(dg_, (int)m, (int)k, ef, static_cast<const char*>(d_queries) + q0 * qbytes,
+                                             ws_bitset_.as<uint32_t>(), ws_old_a_.as<float>(), ws_old_r_.as<int32_t>(),
+                                             d_ids + q0 * k, d_dists + q0 * k, cnt2 + q0, ws_ndc_.as<int32_t>() + ctr_off_ + q0,
+                                             ws_hops_.as<int32_t>() + ctr_off_ + q0, ws_hops_up_.as<int32_t>() + ctr_off_ + q0,
+                                             ws_status_.as<int32_t>() + ctr_off_ + q0, stream),
+                      "hnsw_search(big)");
+            if (q0 + slice >= nq) prof_end(stream);
+        }
+        return;
+    }
     int32_t* cnt = d_cnt;
     if (!cnt) {
         ws_outcnt_.ensure(nq * 4);

@@ -2244,76 +2244,140 @@ __global__ __launch_bounds__(256) void bf_rerank_f32_list_kernel(RerankListF32Ar
     // the order of its xor-32 and xor-16 steps, and the xor 8 / 4 / 2 / 1 steps run across the 16 lanes.
     const float* qq = a.queries + (size_t)q * a.ldb;
     const int sub = lane & 15, rg = lane >> 4;
-    // lane `sub` of a row's 16 lanes plays the virtual lanes v = sub, sub + 16, sub + 32, sub + 48 of
-    // wave_exact_distance_f32: virtual lane v runs ONE fma chain over the dimensions v, v + 64, v + 128, ... (any row
-    // length since round 3: two 64-dimension steps per pass, the chains carried across the passes)
-    const int nstep = (a.dim + 63) >> 6;
-    for (int j0 = wave * 16; j0 < total; j0 += 64) {
-        uint32_t pos[4];
-        const float* rowp[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int j = j0 + 4 * u + rg;
-            pos[u] = (uint32_t)keys[j < total ? j : total - 1];
-            rowp[u] = a.base + (size_t)pos[u] * a.ldb + sub;
+    if (a.dim <= 128) {
+        // (rows of up to 128 dimensions: every load of a round issued up front -- the shape this kernel was tuned in)
+        float qv[8];
+        bool ok[8];
+    #pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const int d = sub + 16 * c;          // c = 0..3: dimension of virtual lane sub + 16c; c = 4..7: the same + 64
+            ok[c] = d < a.dim;
+            qv[c] = ok[c] ? qq[d] : 0.f;
         }
-        float p0[4][4], p1[4][4], p2[4][4];   // [row][virtual lane]
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-            for (int v = 0; v < 4; ++v) p0[u][v] = p1[u][v] = p2[u][v] = 0.f;
-        for (int c0 = 0; c0 < nstep; c0 += 2) {
-            float xv[4][8], qv[8];
-            bool ok[8];
-#pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const int d = sub + 16 * (c & 3) + 64 * (c0 + (c >> 2));   // c = 0..3: step c0, c = 4..7: step c0 + 1
-                ok[c] = d < a.dim;
-                qv[c] = ok[c] ? qq[d] : 0.f;
-#pragma unroll
-                for (int u = 0; u < 4; ++u) xv[u][c] = ok[c] ? rowp[u][16 * (c & 3) + 64 * (c0 + (c >> 2))] : 0.f;
-            }
-#pragma unroll
+        for (int j0 = wave * 16; j0 < total; j0 += 64) {
+            uint32_t pos[4];
+            float xv[4][8];
+    #pragma unroll
             for (int u = 0; u < 4; ++u) {
-#pragma unroll
+                const int j = j0 + 4 * u + rg;
+                pos[u] = (uint32_t)keys[j < total ? j : total - 1];
+                const float* row = a.base + (size_t)pos[u] * a.ldb + sub;
+    #pragma unroll
+                for (int c = 0; c < 8; ++c) xv[u][c] = ok[c] ? row[16 * c] : 0.f;
+            }
+            __builtin_amdgcn_wave_barrier();
+    #pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                float p0[4], p1[4], p2[4];   // per virtual lane: the fma chain over dimensions v, v + 64
+    #pragma unroll
                 for (int v = 0; v < 4; ++v) {
-#pragma unroll
+                    p0[v] = p1[v] = p2[v] = 0.f;
+    #pragma unroll
                     for (int c = 0; c < 2; ++c) {
-                        if (64 * (c0 + c) >= a.dim) continue;    // (wave_exact_distance_f32 stops at the last 64-chunk)
+                        if (64 * c >= a.dim) continue;    // (wave_exact_distance_f32 stops at the last 64-chunk)
                         const float x = xv[u][v + 4 * c], y = qv[v + 4 * c];
                         if (a.space == SP_L2) {
                             const float t = x - y;
-                            p0[u][v] = fmaf(t, t, p0[u][v]);
+                            p0[v] = fmaf(t, t, p0[v]);
                         } else {
-                            p0[u][v] = fmaf(x, y, p0[u][v]);
+                            p0[v] = fmaf(x, y, p0[v]);
                             if (a.space != SP_NEGDOT) {
-                                p1[u][v] = fmaf(x, x, p1[u][v]);
-                                p2[u][v] = fmaf(y, y, p2[u][v]);
+                                p1[v] = fmaf(x, x, p1[v]);
+                                p2[v] = fmaf(y, y, p2[v]);
+                            }
+                        }
+                    }
+                }
+                auto tree = [&](const float* p) __attribute__((always_inline)) -> float {
+                    float s = (p[0] + p[2]) + (p[1] + p[3]);     // xor 32, then xor 16
+    #pragma unroll
+                    for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+                    return s;
+                };
+                const float s0 = tree(p0);
+                float d;
+                if (a.space == SP_L2) d = sqrtf(s0);
+                else if (a.space == SP_NEGDOT) d = -s0;
+                else {
+                    const float sim = normdot_finish(s0, tree(p1), tree(p2));
+                    d = a.space == SP_ANGULAR ? acosf(sim) : fmaxf(0.0f, 1.0f - sim);
+                }
+                const int j = j0 + 4 * u + rg;
+                if (sub == 0 && j < total) keys[j] = ((u64)f32_ord(d) << 32) | pos[u];
+            }
+        }
+    } else {
+        // lane `sub` of a row's 16 lanes plays the virtual lanes v = sub, sub + 16, sub + 32, sub + 48 of
+        // wave_exact_distance_f32: virtual lane v runs ONE fma chain over the dimensions v, v + 64, v + 128, ... (any row
+        // length since round 3: two 64-dimension steps per pass, the chains carried across the passes)
+        const int nstep = (a.dim + 63) >> 6;
+        for (int j0 = wave * 16; j0 < total; j0 += 64) {
+            uint32_t pos[4];
+            const float* rowp[4];
+    #pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = j0 + 4 * u + rg;
+                pos[u] = (uint32_t)keys[j < total ? j : total - 1];
+                rowp[u] = a.base + (size_t)pos[u] * a.ldb + sub;
+            }
+            float p0[4][4], p1[4][4], p2[4][4];   // [row][virtual lane]
+    #pragma unroll
+            for (int u = 0; u < 4; ++u)
+    #pragma unroll
+                for (int v = 0; v < 4; ++v) p0[u][v] = p1[u][v] = p2[u][v] = 0.f;
+            for (int c0 = 0; c0 < nstep; c0 += 2) {
+                float xv[4][8], qv[8];
+                bool ok[8];
+    #pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const int d = sub + 16 * (c & 3) + 64 * (c0 + (c >> 2));   // c = 0..3: step c0, c = 4..7: step c0 + 1
+                    ok[c] = d < a.dim;
+                    qv[c] = ok[c] ? qq[d] : 0.f;
+    #pragma unroll
+                    for (int u = 0; u < 4; ++u) xv[u][c] = ok[c] ? rowp[u][16 * (c & 3) + 64 * (c0 + (c >> 2))] : 0.f;
+                }
+    #pragma unroll
+                for (int u = 0; u < 4; ++u) {
+    #pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+    #pragma unroll
+                        for (int c = 0; c < 2; ++c) {
+                            if (64 * (c0 + c) >= a.dim) continue;    // (wave_exact_distance_f32 stops at the last 64-chunk)
+                            const float x = xv[u][v + 4 * c], y = qv[v + 4 * c];
+                            if (a.space == SP_L2) {
+                                const float t = x - y;
+                                p0[u][v] = fmaf(t, t, p0[u][v]);
+                            } else {
+                                p0[u][v] = fmaf(x, y, p0[u][v]);
+                                if (a.space != SP_NEGDOT) {
+                                    p1[u][v] = fmaf(x, x, p1[u][v]);
+                                    p2[u][v] = fmaf(y, y, p2[u][v]);
+                                }
                             }
                         }
                     }
                 }
             }
-        }
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            auto tree = [&](const float* p) __attribute__((always_inline)) -> float {
-                float s = (p[0] + p[2]) + (p[1] + p[3]);     // xor 32, then xor 16
-#pragma unroll
-                for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-                return s;
-            };
-            const float s0 = tree(p0[u]);
-            float d;
-            if (a.space == SP_L2) d = sqrtf(s0);
-            else if (a.space == SP_NEGDOT) d = -s0;
-            else {
-                const float sim = normdot_finish(s0, tree(p1[u]), tree(p2[u]));
-                d = a.space == SP_ANGULAR ? acosf(sim) : fmaxf(0.0f, 1.0f - sim);
+            __builtin_amdgcn_wave_barrier();
+    #pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                auto tree = [&](const float* p) __attribute__((always_inline)) -> float {
+                    float s = (p[0] + p[2]) + (p[1] + p[3]);     // xor 32, then xor 16
+    #pragma unroll
+                    for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+                    return s;
+                };
+                const float s0 = tree(p0[u]);
+                float d;
+                if (a.space == SP_L2) d = sqrtf(s0);
+                else if (a.space == SP_NEGDOT) d = -s0;
+                else {
+                    const float sim = normdot_finish(s0, tree(p1[u]), tree(p2[u]));
+                    d = a.space == SP_ANGULAR ? acosf(sim) : fmaxf(0.0f, 1.0f - sim);
+                }
+                const int j = j0 + 4 * u + rg;
+                if (sub == 0 && j < total) keys[j] = ((u64)f32_ord(d) << 32) | pos[u];
             }
-            const int j = j0 + 4 * u + rg;
-            if (sub == 0 && j < total) keys[j] = ((u64)f32_ord(d) << 32) | pos[u];
         }
     }
     for (int i = total + tid; i < P; i += blockDim.x) keys[i] = ~0ull;

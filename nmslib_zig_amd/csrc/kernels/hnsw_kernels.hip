@@ -979,6 +979,272 @@ __global__ __launch_bounds__(64) void hnsw_search_old_kernel(HnswArgs a, OldWs w
 }
 
 // ---------------------------------------------------------------------------------------
+// SearchV1Merge with a sorted array beyond the LDS kernels' 1024 items (round 3; only reachable with an explicit
+// algoType=v1merge and efSearch > 1024, or k > 1024 below efSearch 1000: hybrid mode runs SearchOld from 1000 on).
+// The reference sizes SortArrBI to max(ef, k) whatever that is (hnsw_distfunc_opt.cc:152-167).  Same algorithm, item for
+// item; the array (keys, id | used << 31) lives in a per-query HBM workspace, the visited set is an HBM bitset, and the
+// accepted items of an expansion are inserted one after the other with SortArrBI::push_or_replace_non_empty_exp
+// (sort_arr_bi.h:159-199) -- no attempt at speed: one wave per query, chunks of 64.
+// ---------------------------------------------------------------------------------------
+template <int SPACE, bool WIDE>
+__global__ __launch_bounds__(64) void hnsw_search_big_kernel(HnswArgs a, float* ws_keys, int* ws_idu) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const HnswDeviceGraph& g = a.g;
+    const int q = blockIdx.x, lane = threadIdx.x;
+    constexpr bool kU8 = DistTraits<SPACE>::kU8;
+    constexpr int nbcap = WIDE ? 128 : 64;
+    const int qfloats = kU8 ? 32 : g.ldv;
+    float* qv = reinterpret_cast<float*>(smem);
+    int* nbr = reinterpret_cast<int*>(qv + qfloats);
+    float* nd = reinterpret_cast<float*>(nbr + nbcap);
+    float* sk = nd + nbcap;
+    int* si = reinterpret_cast<int*>(sk + 64);
+    float* keys = ws_keys + (size_t)q * a.cap;
+    int* idu = ws_idu + (size_t)q * a.cap;
+    uint32_t* bits = a.bitset + (size_t)q * a.bitset_words;
+
+    int qnorm = 0;
+    if constexpr (kU8) {
+        const uint8_t* src = reinterpret_cast<const uint8_t*>(a.queries) + (size_t)q * 128;
+        const int x0 = src[2 * lane], x1 = src[2 * lane + 1];
+        reinterpret_cast<uint8_t*>(qv)[2 * lane] = (uint8_t)x0;
+        reinterpret_cast<uint8_t*>(qv)[2 * lane + 1] = (uint8_t)x1;
+        qnorm = wave_sum_i(x0 * x0 + x1 * x1);
+    } else {
+        const float* src = reinterpret_cast<const float*>(a.queries) + (size_t)q * g.dim;
+        float ss = 0.f;
+        for (int d = lane; d < g.ldv; d += 64) {
+            const float v = d < g.dim ? src[d] : 0.f;
+            qv[d] = v;
+            ss = fmaf(v, v, ss);
+        }
+        if (g.normalize_query) {
+            ss = wave_sum(ss);
+            if (ss != 0.0f) {
+                const float inv = 1.0f / sqrtf(ss);
+                for (int d = lane; d < g.dim; d += 64) qv[d] *= inv;
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    const uint8_t* qb = reinterpret_cast<const uint8_t*>(qv);
+    auto visit = [&](uint32_t id) -> bool {
+        const uint32_t bit = 1u << (id & 31);
+        return (atomicOr(&bits[id >> 5], bit) & bit) == 0;
+    };
+    int ndc = 0, hops = 0, hops_up = 0;
+    if (g.n == 0) {
+        for (int i = lane; i < a.k; i += 64) {
+            a.out_ids[(size_t)q * a.k + i] = -1;
+            a.out_dists[(size_t)q * a.k + i] = INFINITY;
+        }
+        if (lane == 0) {
+            a.out_cnt[q] = 0;
+            if (a.out_ndc) a.out_ndc[q] = 0;
+            if (a.out_hops) a.out_hops[q] = 0;
+            if (a.out_hops_up) a.out_hops_up[q] = 0;
+            if (a.status) a.status[q] = 0;
+        }
+        return;
+    }
+    // ---- entry point + greedy descent (hnsw_distfunc_opt.cc:168-198) ----
+    int cur = g.enterpoint;
+    if (lane == 0) nbr[0] = cur;
+    __builtin_amdgcn_wave_barrier();
+    frontier_distances<SPACE>(g, qv, qb, qnorm, nbr, nd, 1, lane);
+    float curdist = nd[0];
+    ndc += 1;
+    for (int lvl = g.maxlevel; lvl > 0; --lvl) {
+        bool changed = true;
+        while (changed) {
+            changed = false;
+            const int64_t off = g.up_off[cur] + (int64_t)(lvl - 1) * (g.maxM + 1);
+            const int v = (lane <= g.maxM) ? g.up_links[off + lane] : 0;
+            const int cntl = __builtin_amdgcn_readfirstlane(v);
+            const int nb = __shfl(v, lane + 1, 64);
+            if (lane < cntl) nbr[lane] = nb;
+            __builtin_amdgcn_wave_barrier();
+            hops_up++;
+            if (cntl > 0) {
+                frontier_distances<SPACE>(g, qv, qb, qnorm, nbr, nd, cntl, lane);
+                ndc += cntl;
+                u64 key = ~0ull;
+                if (lane < cntl) key = ((u64)f32_ord(nd[lane]) << 32) | (uint32_t)lane;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    const u64 other = __shfl_xor(key, o, 64);
+                    key = other < key ? other : key;
+                }
+                const float dmin = ord_f32((uint32_t)(key >> 32));
+                if (dmin < curdist) {
+                    curdist = dmin;
+                    cur = nbr[(uint32_t)key];
+                    changed = true;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    // ---- level 0 (hnsw_distfunc_opt.cc:200-274) ----
+    int n = 1, cursor = 0;
+    if (lane == 0) {
+        keys[0] = curdist;
+        idu[0] = cur;
+        (void)visit((uint32_t)cur);
+    }
+    wave_sync();
+    while (true) {
+        const int lim = n < a.ef ? n : a.ef;
+        int fu = n;
+        for (int base = cursor; base < lim && fu == n; base += 64) {
+            const int i = base + lane;
+            const u64 mk = __ballot(i < n && idu[i] >= 0);
+            if (mk) fu = base + (__ffsll((long long)mk) - 1);
+        }
+        if (fu >= lim) break;
+        const int c = idu[fu] & 0x7FFFFFFF;
+        wave_sync();
+        if (lane == 0) idu[fu] |= (int)0x80000000;
+        cursor = fu + 1;
+        hops++;
+        const float topKey = keys[n - 1];
+        const int size0 = n;
+        wave_sync();
+        // adjacency [count][ids...] -> unvisited neighbours
+        const int v = (lane <= g.maxM0) ? g.links0[(size_t)c * (g.maxM0 + 1) + lane] : 0;
+        const int cntn = __builtin_amdgcn_readfirstlane(v);
+        const int nb = __shfl(v, lane + 1, 64);
+        bool isn = false;
+        if (lane < cntn && (!WIDE || lane < 63)) isn = visit((uint32_t)nb);
+        const u64 nmask = __ballot(isn);
+        int m = __popcll(nmask);
+        if (isn) nbr[__popcll(nmask & ((1ull << lane) - 1ull))] = nb;
+        if (WIDE && cntn > 63) {
+            int nb2 = 0;
+            if (64 + lane <= g.maxM0) nb2 = g.links0[(size_t)c * (g.maxM0 + 1) + 64 + lane];
+            bool isn2 = false;
+            if (63 + lane < cntn) isn2 = visit((uint32_t)nb2);
+            const u64 nmask2 = __ballot(isn2);
+            if (isn2) nbr[m + __popcll(nmask2 & ((1ull << lane) - 1ull))] = nb2;
+            m += __popcll(nmask2);
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (m == 0) continue;
+        ndc += m;
+        frontier_distances<SPACE>(g, qv, qb, qnorm, nbr, nd, m, lane);
+        for (int r0 = 0; r0 < m; r0 += 64) {
+            float dj = INFINITY;
+            int idj = -1;
+            bool acc = false;
+            if (r0 + lane < m) {
+                dj = nd[r0 + lane];
+                idj = nbr[r0 + lane];
+                acc = (dj < topKey) || (size0 < a.ef);
+            }
+            const u64 amask = __ballot(acc);
+            const int m2 = __popcll(amask);
+            if (m2 == 0) continue;
+            int rank = 0;
+            for (u64 mm = amask; mm;) {
+                const int j = __ffsll((long long)mm) - 1;
+                mm &= mm - 1;
+                const float dother = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dj), j));
+                rank += ((dother < dj) | ((dother == dj) & (j < lane))) ? 1 : 0;
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (acc) {
+                sk[rank] = dj;
+                si[rank] = idj;
+            }
+            __builtin_amdgcn_wave_barrier();
+            for (int t = 0; t < m2; ++t) {   // push_or_replace_non_empty_exp, in ascending order (:251-266)
+                const float key = sk[t];
+                const int id = si[t];
+                const float lastk = keys[n - 1];
+                if (lastk <= key) {
+                    if (n < a.cap) {
+                        if (lane == 0) {
+                            keys[n] = key;
+                            idu[n] = id;
+                        }
+                        n++;
+                    }
+                    wave_sync();
+                    continue;
+                }
+                int less = 0, leq = 0;
+                for (int base = 0; base < n; base += 64) {
+                    const int i = base + lane;
+                    const float kv = i < n ? keys[i] : INFINITY;
+                    less += __popcll(__ballot(kv < key));
+                    leq += __popcll(__ballot(kv <= key));
+                }
+                int p = less;
+                if (leq != less) {   // an equal key in the array: replay the probe (:172-186)
+                    int curr = n - 1, prev = curr, dstep = 1;
+                    while (curr > 0 && keys[curr] > key) {
+                        prev = curr;
+                        curr -= dstep;
+                        dstep *= 2;
+                        if (dstep > curr) dstep = curr;
+                    }
+                    p = curr;
+                    for (int i = curr; i < prev && keys[i] < key; ++i) p = i + 1;
+                }
+                const int newn = n < a.cap ? n + 1 : a.cap;
+                // shift [p, newn - 1) up by one: chunks from the top down, every chunk read before it is written
+                for (int base = ((newn - 1) / 64) * 64; base >= 0 && base + 64 > p; base -= 64) {
+                    const int i = base + lane;
+                    const bool mv = i > p && i < newn;
+                    float kv = 0.f;
+                    int iv = 0;
+                    if (mv) {
+                        kv = keys[i - 1];
+                        iv = idu[i - 1];
+                    }
+                    wave_sync();
+                    if (mv) {
+                        keys[i] = kv;
+                        idu[i] = iv;
+                    }
+                    wave_sync();
+                }
+                if (lane == 0) {
+                    keys[p] = key;
+                    idu[p] = id;
+                }
+                n = newn;
+                if (p < cursor) cursor = p;
+                wave_sync();
+            }
+        }
+    }
+    wave_sync();
+    const int kk = a.k < n ? a.k : n;
+    for (int i = lane; i < a.k; i += 64) {
+        if (i < kk) {
+            const float ki = keys[i];
+            const int id = idu[i] & 0x7FFFFFFF;
+            int r = i;
+            for (int j = i - 1; j >= 0 && keys[j] == ki; --j) r -= ((idu[j] & 0x7FFFFFFF) > id) ? 1 : 0;
+            for (int j = i + 1; j < kk && keys[j] == ki; ++j) r += ((idu[j] & 0x7FFFFFFF) < id) ? 1 : 0;
+            a.out_ids[(size_t)q * a.k + r] = g.ext_ids ? g.ext_ids[id] : id;
+            a.out_dists[(size_t)q * a.k + r] = ki;
+        } else {
+            a.out_ids[(size_t)q * a.k + i] = -1;
+            a.out_dists[(size_t)q * a.k + i] = INFINITY;
+        }
+    }
+    if (lane == 0) {
+        a.out_cnt[q] = kk;
+        if (a.out_ndc) a.out_ndc[q] = ndc;
+        if (a.out_hops) a.out_hops[q] = hops;
+        if (a.out_hops_up) a.out_hops_up[q] = hops_up;
+        if (a.status) a.status[q] = 0;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // Host side
 // ---------------------------------------------------------------------------------------
 static int ilog2(int v) {
@@ -1254,6 +1520,52 @@ hipError_t launch_hnsw_search_old(const HnswDeviceGraph& g, const HnswSearchPlan
         case SP_ANGULAR: return launch_old_space<SP_ANGULAR>(a, w, p, s);
         case SP_NEGDOT: return launch_old_space<SP_NEGDOT>(a, w, p, s);
         case SP_L2SQR_SIFT: return launch_old_space<SP_L2SQR_SIFT>(a, w, p, s);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+
+// ---- SearchV1Merge beyond 1024 items (hnsw_search_big_kernel) ---------------------------------------------------
+template <int SPACE>
+static hipError_t launch_big_space(const HnswArgs& a, float* ws_keys, int32_t* ws_idu, size_t lds, hipStream_t s) {
+    if (a.g.maxM0 > 62) hipLaunchKernelGGL((hnsw_search_big_kernel<SPACE, true>), dim3(a.nq), dim3(64), lds, s, a, ws_keys, ws_idu);
+    else hipLaunchKernelGGL((hnsw_search_big_kernel<SPACE, false>), dim3(a.nq), dim3(64), lds, s, a, ws_keys, ws_idu);
+    return hipGetLastError();
+}
+
+hipError_t launch_hnsw_search_big(const HnswDeviceGraph& g, int nq, int k, int ef, const void* queries, uint32_t* bitset,
+                                  float* ws_keys, int32_t* ws_idu, int32_t* out_ids, float* out_dists, int32_t* out_cnt,
+                                  int32_t* out_ndc, int32_t* out_hops, int32_t* out_hops_up, int32_t* status, hipStream_t s) {
+    if (nq == 0) return hipSuccess;
+    if (g.maxM0 > 126 || g.maxM > 62) return hipErrorInvalidValue;
+    HnswArgs a{};
+    a.g = g;
+    a.queries = queries;
+    a.bitset = bitset;
+    a.bitset_words = ((size_t)g.n + 31) / 32;
+    a.out_ids = out_ids;
+    a.out_dists = out_dists;
+    a.out_cnt = out_cnt;
+    a.out_ndc = out_ndc;
+    a.out_hops = out_hops;
+    a.out_hops_up = out_hops_up;
+    a.status = status;
+    a.nq = nq;
+    a.k = k;
+    a.ef = ef;
+    a.cap = ef > k ? ef : k;
+    const bool u8 = g.space == SP_L2SQR_SIFT;
+    const size_t lds = (u8 ? 128 : (size_t)g.ldv * 4) + (size_t)(2 * (g.maxM0 > 62 ? 128 : 64) + 2 * 64) * 4 + 16;
+    switch (g.space) {
+        case SP_L2SQR: return launch_big_space<SP_L2SQR>(a, ws_keys, ws_idu, lds, s);
+        case SP_L2: return launch_big_space<SP_L2>(a, ws_keys, ws_idu, lds, s);
+        case SP_L1: return launch_big_space<SP_L1>(a, ws_keys, ws_idu, lds, s);
+        case SP_LINF: return launch_big_space<SP_LINF>(a, ws_keys, ws_idu, lds, s);
+        case SP_NORMCOS: return launch_big_space<SP_NORMCOS>(a, ws_keys, ws_idu, lds, s);
+        case SP_COSINE: return launch_big_space<SP_COSINE>(a, ws_keys, ws_idu, lds, s);
+        case SP_ANGULAR: return launch_big_space<SP_ANGULAR>(a, ws_keys, ws_idu, lds, s);
+        case SP_NEGDOT: return launch_big_space<SP_NEGDOT>(a, ws_keys, ws_idu, lds, s);
+        case SP_L2SQR_SIFT: return launch_big_space<SP_L2SQR_SIFT>(a, ws_keys, ws_idu, lds, s);
         default: return hipErrorInvalidValue;
     }
 }

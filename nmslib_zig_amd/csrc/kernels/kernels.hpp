@@ -232,6 +232,12 @@ hipError_t launch_hnsw_search(const HnswDeviceGraph& g, const HnswSearchPlan& p,
                               int32_t* out_hops, int32_t* out_hops_up, int32_t* status,
                               hipStream_t s);
 
+// SearchV1Merge with max(ef, k) beyond the LDS kernels' 1024 items: the sorted array in a per-query HBM workspace
+// (ws_keys / ws_idu: [nq][max(ef, k)]), visited set = HBM bitset [nq][ceil(n / 32)] (cleared by the caller).
+hipError_t launch_hnsw_search_big(const HnswDeviceGraph& g, int nq, int k, int ef, const void* queries, uint32_t* bitset,
+                                  float* ws_keys, int32_t* ws_idu, int32_t* out_ids, float* out_dists, int32_t* out_cnt,
+                                  int32_t* out_ndc, int32_t* out_hops, int32_t* out_hops_up, int32_t* status, hipStream_t s);
+
 // Visited-table overflow handled on the device (no host round trip):
 //   1. LDS-table plan:  fix_slots = 0, fix_list/fix_count given -> overflowed queries are appended to fix_list;
 //   2. bitset plan:     fix_slots = S > 0 -> S workgroups walk fix_list (count read on the device), each clearing and

@@ -84,9 +84,10 @@ def main():
     stats["per_kernel"] = dict(sorted(per_kernel.items(), key=lambda kv: -kv[1]["total_us"]))
     json.dump(stats, open(os.path.join(out, f"{tag}_{workload}_stats.json"), "w"), indent=1)
     # keep rocprofv3's own summary, drop the raw traces (gpurun copies back at most 64 MiB)
-    for f in glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True):
+    trace_dir = os.path.join(out, f"{tag}_{workload}_trace")
+    for f in glob.glob(os.path.join(trace_dir, "**", "*kernel_stats.csv"), recursive=True):
         shutil.copy(f, os.path.join(out, f"{tag}_{workload}_rocprofv3_kernel_stats.csv"))
-    shutil.rmtree(d, ignore_errors=True)
+    shutil.rmtree(trace_dir, ignore_errors=True)
 
     # ---- counter passes ----
     pmc = {}
