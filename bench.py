@@ -366,7 +366,7 @@ def run_workload(a, name, cx):
         # bytes/query = ndc*D*4 + hops0*(maxM0+1)*4 + hops_up*(maxM+1)*4 + ndc (visited)
         alg_bytes = float((ndc * dim * 4 + hops * 33 * 4 + hops_up * 17 * 4 + ndc).sum())
         roof = {"bound": "hbm", "achieved": round(alg_bytes / kern_s / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                "kernel": ("hnsw_search_mw_kernel" if nq <= 2048 and a.ef <= 256 and os.environ.get("NMSLIB_HNSW_MW", "1") != "0"
+                "kernel": ("hnsw_search_mw_kernel" if a.ef <= 256 and os.environ.get("NMSLIB_HNSW_MW", "1") != "0"
                            else ("hnsw_search_old_kernel" if a.ef >= 1000 else "hnsw_search_kernel")),
                 "ndc_per_query": round(float(ndc.mean()), 1), "hops_per_query": round(float(hops.mean()), 1),
                 "kernel_launches_per_step": round(launches / max(1, a.steps), 2)}
