@@ -1356,6 +1356,7 @@ size_t Engine::range_host(const void* query, size_t elem_count, double radius, s
     if (elem_count != dim_) throw EngineError(Err::QueryExecutionFailed, "query dimension does not match the index");
     if (!shards_.empty()) {
         // insertion order = shard order; shards report global positions
+        DeviceGuard guard(device_);   // (a shard that throws must not leave this thread on its device)
         size_t got = 0;
         for (auto& c : shards_) {
             if (got >= capacity) break;

@@ -1301,7 +1301,7 @@ static hipError_t launch_space_w(const HnswArgs& a, const HnswSearchPlan& p, hip
             const char* eq = getenv("NMSLIB_HNSW_MW_MAXQ");
             const int mode = em ? atoi(em) : 1;
             const int max_nq = eq ? atoi(eq) : 0x7fffffff;
-            if (mode && !a.query_rows && !a.start_nodes && a.level == 0 && (mode == 2 || a.nq <= max_nq)) {
+            if (mode && (mode == 2 || a.nq <= max_nq)) {   // (construction mode included: stored rows as queries, any level)
                 const hipError_t me = launch_hnsw_search_mw(a, p.lds_bytes + 16, EMAX, s);
                 if (me != hipSuccess) return me;
                 return hipGetLastError();

@@ -201,19 +201,26 @@ __device__ __forceinline__ void mw_control(const HnswArgs& a, const int q, float
         nvisited += m;
         return m;
     };
+    // adjacency list of node c on the level being searched, shifted by one word: lane L holds neighbour L, the last
+    // lanes hold the count (word 0).  (level > 0: the search step of the graph construction, hnsw_build_kernels.hip)
     auto load_adj0 = [&](int c) __attribute__((always_inline)) -> int {
-        const int w = lane + 1 <= g.maxM0 ? lane + 1 : 0;
-        return g.links0[(size_t)c * (g.maxM0 + 1) + w];
+        if (a.level == 0) {
+            const int w = lane + 1 <= g.maxM0 ? lane + 1 : 0;
+            return g.links0[(size_t)c * (g.maxM0 + 1) + w];
+        }
+        const int w = lane + 1 <= g.maxM ? lane + 1 : 0;
+        return g.up_links[g.up_off[c] + (int64_t)(a.level - 1) * (g.maxM + 1) + w];
     };
     // ---- entry point + greedy descent (hnsw_distfunc_opt.cc:168-198) ----
-    int cur = g.enterpoint;
+    const int start = a.start_nodes ? a.start_nodes[q] : -1;   // construction mode: a given start node, or descend to level + 1
+    int cur = start >= 0 ? start : g.enterpoint;
     nbr[lane] = cur;
     ctl[0] = 1;
     mw_barrier();  // A
     mw_barrier();  // B
     float curdist = nd[0];
     ndc += 1;
-    for (int lvl = g.maxlevel; lvl > 0; --lvl) {
+    for (int lvl = (start >= 0 ? 0 : g.maxlevel); lvl > a.level; --lvl) {
         bool changed = true;
         while (changed) {
             changed = false;
@@ -589,7 +596,8 @@ __global__ __launch_bounds__(MW_THREADS) void hnsw_search_mw_kernel(HnswArgs a) 
     }
     // ---- stage the query, clear the visited table (all waves) ----
     {
-        const float* src = reinterpret_cast<const float*>(a.queries) + (size_t)q * g.dim;
+        const float* src = a.query_rows ? reinterpret_cast<const float*>(g.rows) + (size_t)a.query_rows[q] * g.ldv
+                                        : reinterpret_cast<const float*>(a.queries) + (size_t)q * g.dim;
         if (wave == 0) {
             float ss = 0.f;
             for (int d = lane; d < g.ldv; d += 64) {
@@ -597,7 +605,7 @@ __global__ __launch_bounds__(MW_THREADS) void hnsw_search_mw_kernel(HnswArgs a) 
                 qv[d] = v;
                 ss = fmaf(v, v, ss);
             }
-            if (g.normalize_query) {  // hnsw_distfunc_opt.cc:160-162
+            if (g.normalize_query && !a.query_rows) {  // hnsw_distfunc_opt.cc:160-162 (stored rows are already normalised)
                 ss = wave_sum(ss);
                 if (ss != 0.0f) {
                     const float inv = 1.0f / sqrtf(ss);

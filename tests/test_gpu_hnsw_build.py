@@ -91,6 +91,22 @@ def test_gpu_build_is_deterministic_and_reloadable(tmp_path):
         i.close()
 
 
+@pytest.mark.parametrize("space,dim", [("l2", 32), ("cosinesimil", 48)])
+def test_gpu_build_same_graph_with_either_search_kernel(space, dim, tmp_path, monkeypatch):
+    """the construction's search step runs the workgroup-per-query kernel (stored rows as queries, any level); the
+    one-wave kernel (NMSLIB_HNSW_MW=0) must produce the same candidates, hence the same graph, bit for bit"""
+    X = refio.s_lowrank(8000, dim, 171)
+    graphs = []
+    for mw in ("0", "1"):
+        monkeypatch.setenv("NMSLIB_HNSW_MW", mw)
+        idx = make_index(space, "hnsw", X, M=8, efConstruction=80, gpu_build=1, gpu_build_batch=512)
+        graphs.append(graph_of(idx, tmp_path, f"mw{mw}.idx"))
+        idx.close()
+    assert graphs[0]["up_links"].size > 0      # (several levels: the search step ran above level 0 too)
+    np.testing.assert_array_equal(graphs[0]["links0"], graphs[1]["links0"])
+    np.testing.assert_array_equal(graphs[0]["up_links"], graphs[1]["up_links"])
+
+
 def test_gpu_build_tiny_and_delaunay0():
     X = refio.s_gauss(40, 8, 81)
     idx = make_index("l2", "hnsw", X, M=4, efConstruction=20, gpu_build=1)
