@@ -68,6 +68,29 @@ __device__ __forceinline__ u64 wave_max_u64(u64 v) {
     return v;
 }
 
+// ascending bitonic sort of 128 64-bit keys held two per lane (element 2 * lane + i), registers and shuffles only: no LDS,
+// no barrier.  Afterwards lane L holds elements 2L and 2L + 1 of the sorted order.
+__device__ __forceinline__ void wave_sort128_u64(u64& k0, u64& k1, int lane) {
+#pragma unroll
+    for (int k2 = 2; k2 <= 128; k2 <<= 1) {
+        const bool asc = ((2 * lane) & k2) == 0;   // (both elements of a lane lie in the same run: k2 >= 2)
+#pragma unroll
+        for (int j = k2 >> 1; j >= 1; j >>= 1) {
+            if (j == 1) {
+                const u64 lo = k0 < k1 ? k0 : k1, hi = k0 < k1 ? k1 : k0;
+                k0 = asc ? lo : hi;
+                k1 = asc ? hi : lo;
+            } else {
+                const int lj = j >> 1;   // the partner element sits in lane ^ lj, same slot
+                const bool keep_min = ((lane & lj) == 0) == asc;
+                const u64 o0 = __shfl_xor(k0, lj, 64), o1 = __shfl_xor(k1, lj, 64);
+                k0 = keep_min ? (o0 < k0 ? o0 : k0) : (o0 > k0 ? o0 : k0);
+                k1 = keep_min ? (o1 < k1 ? o1 : k1) : (o1 > k1 ? o1 : k1);
+            }
+        }
+    }
+}
+
 __device__ __forceinline__ u64 gather_key(const u64* g, int idx, int n0, int n1, int half) {
     if (idx < n0) return g[idx];
     if (idx - n0 < n1) return g[half + idx - n0];
@@ -957,15 +980,22 @@ __device__ __forceinline__ uint32_t hit_mask_i32(const i32x16& c, int t) {
 }
 // list s = (split, half) of query q: entries -> row positions at keys[offs[s] ..]; one thread per list (a handful of
 // entries each).  offs[] holds the prefix sums of the lists' POSITION counts (list_cnt), none above caph here.
+// Entry i of the query's lists is one contiguous plane [list] (round 3; a list per cache line before: the re-rank
+// fetched 2 * nsplit lines per query for one or two entries each -- 33 MB at C2, 12 us): the threads of a wave read
+// neighbouring words, and the first four planes are requested together (an entry lists at least one row, so entry
+// i < len exists or is never looked at).
 __device__ __forceinline__ void scan_gather_entries(u64* keys, const int* offs, const uint32_t* list, int q, int nl, int caph,
                                                     int tps, int tid, int nthreads) {
     for (int s = tid; s < nl; s += nthreads) {
         const int len = offs[s + 1] - offs[s];
-        const uint32_t* e = list + ((size_t)q * nl + s) * caph;
+        if (len == 0) continue;
+        const uint32_t* e = list + (size_t)q * caph * nl + s;
         const uint32_t row_base = (uint32_t)(s >> 1) * (uint32_t)tps * BF_BN + 4u * (s & 1);
+        uint32_t pre[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pre[i] = (i < len && i < caph) ? e[(size_t)i * nl] : 0u;
         int j = 0;
-        for (int i = 0; i < caph && j < len; ++i) {
-            const uint32_t ent = e[i];
+        auto expand = [&](const uint32_t ent) __attribute__((always_inline)) {
             uint32_t m = ent & 0xffffu;
             const uint32_t r0 = row_base + (ent >> 16) * 32u;
             while (m && j < len) {
@@ -974,7 +1004,11 @@ __device__ __forceinline__ void scan_gather_entries(u64* keys, const int* offs, 
                 const int reg = 15 - bit;
                 keys[offs[s] + j++] = (u64)(r0 + (reg & 3) + 8 * (reg >> 2));
             }
-        }
+        };
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (i < caph && j < len) expand(pre[i]);
+        for (int i = 4; i < caph && j < len; ++i) expand(e[(size_t)i * nl]);
     }
 }
 
@@ -999,7 +1033,7 @@ struct BfScanArgs {
     const int32_t* auxh;      // [n_pad] aux >> 1 (pad rows: -2^29)
     const uint8_t* queries;   // [qpad][128]
     const int* thr;           // [qpad] pass <=> dot' + auxh >= thr
-    uint32_t* list;           // [qpad][nsplit][2][caph] hit entries: block << 16 | row mask (see hit_mask_i32)
+    uint32_t* list;           // [qpad][caph][nsplit][2] hit entries: block << 16 | row mask (see hit_mask_i32)
     int* list_cnt;            // [qpad][nsplit][2] rows listed
     int n, nqt, nsplit, tps, caph;
     int tile_stride;          // SAMPLE: every tile_stride-th tile
@@ -1069,7 +1103,7 @@ __global__ __launch_bounds__(256, 2) void bf_scan_u8_kernel(BfScanArgs a) {
             for (int i = 0; i < 8; ++i) t8[g][i] = -(1 << 28);
         } else {
             thr[g] = a.thr[qidx];
-            lp[g] = a.list + (((size_t)qidx * a.nsplit + split) * 2 + h) * a.caph;
+            lp[g] = a.list + (size_t)qidx * a.caph * (2 * a.nsplit) + split * 2 + h;   // entry i of a list: [q][i][list]
         }
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): retire the query loads before any DMA is counted
@@ -1115,7 +1149,7 @@ __global__ __launch_bounds__(256, 2) void bf_scan_u8_kernel(BfScanArgs a) {
             if (__builtin_expect(__any(m0 >= tg), 0)) {
                 const uint32_t k0 = hit_mask_i32(c0, tg);
                 if (k0) {
-                    if (ecnt[g] < a.caph) lp[g][ecnt[g]] = (blk << 16) | k0;
+                    if (ecnt[g] < a.caph) lp[g][(size_t)ecnt[g] * (2 * a.nsplit)] = (blk << 16) | k0;
                     ecnt[g]++;
                     cnt[g] += __builtin_popcount(k0);
                 }
@@ -1123,7 +1157,7 @@ __global__ __launch_bounds__(256, 2) void bf_scan_u8_kernel(BfScanArgs a) {
             if (__builtin_expect(__any(m1 >= tg), 0)) {
                 const uint32_t k1 = hit_mask_i32(c1, tg);
                 if (k1) {
-                    if (ecnt[g] < a.caph) lp[g][ecnt[g]] = ((blk + 1) << 16) | k1;
+                    if (ecnt[g] < a.caph) lp[g][(size_t)ecnt[g] * (2 * a.nsplit)] = ((blk + 1) << 16) | k1;
                     ecnt[g]++;
                     cnt[g] += __builtin_popcount(k1);
                 }
@@ -1189,28 +1223,45 @@ __global__ __launch_bounds__(256, 2) void bf_scan_u8_kernel(BfScanArgs a) {
     }
 }
 
-// r-th best value of the sample (union of the lanes' top-8 lists) -> scan threshold of each query; one wave per query.
+// r-th largest of the 64 * NPER ordered keys a wave holds (key[i] of every lane; 0 = "no value", below every real key):
+// bit by bit from the top, the largest T that at least r keys reach.  The counts are scalar (ballot + popcount): no LDS,
+// no barrier, no sort -- a threshold needs ONE order statistic of the sample, not its order.  (Round 3; the workgroup-wide
+// bitonic sort of the 512 / 1024 keys took 18 us at C2 and 40 us at C4.)  Fewer than r real keys: 0.
+template <int NPER>
+__device__ __forceinline__ uint32_t wave_rth_largest_u32(const uint32_t (&key)[NPER], int r) {
+    uint32_t T = 0;
+    for (int b = 31; b >= 0; --b) {
+        const uint32_t cand = T | (1u << b);
+        int c = 0;
+#pragma unroll
+        for (int i = 0; i < NPER; ++i) c += __popcll(__builtin_amdgcn_ballot_w64(key[i] >= cand));
+        if (c >= r) T = cand;
+    }
+    return T;
+}
+
+// r-th best value of the sample (union of the lanes' top-8 lists) -> scan threshold of each query; one wave per query
+// (four queries per workgroup), the sample's values in registers.
 // Any value works as a threshold -- the re-rank verifies the outcome -- this one makes ~r * stride rows pass.
-__global__ __launch_bounds__(256) void bf_u8_threshold_kernel(const int* top8, int nlists, int r, int nq, int* thr) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    u64* keys = reinterpret_cast<u64*>(smem);
-    const int q = blockIdx.x, tid = threadIdx.x;
+template <int NPER>
+__global__ __launch_bounds__(256) void bf_u8_threshold_kernel(const int* top8, int nlists, int r, int nq, int qpad, int* thr) {
+    const int lane = threadIdx.x & 63, q = blockIdx.x * 4 + (threadIdx.x >> 6);
     constexpr int kPassAll = -(1 << 28);  // below every real value, above the pad rows' -2^29
+    if (q >= qpad) return;
     if (q >= nq) {                        // padding queries: nothing may pass
-        if (tid == 0) thr[q] = 0x7FFFFFFF;
+        if (lane == 0) thr[q] = 0x7FFFFFFF;
         return;
     }
     const int total = nlists * 8;
-    const int P = next_pow2(total < 2 ? 2 : total);
-    // ascending sort of the complemented order keys = descending by value
-    for (int i = tid; i < P; i += blockDim.x) keys[i] = i < total ? (u64)(~i32_ord(top8[(size_t)q * total + i])) : ~0ull;
-    __syncthreads();
-    block_bitonic_u64_asc(keys, P, tid, blockDim.x);
-    if (tid == 0) {
-        int t = kPassAll;
-        if (total >= r) t = max(kPassAll, ord_i32(~(uint32_t)keys[r - 1]));
-        thr[q] = t;
+    uint32_t key[NPER];
+#pragma unroll
+    for (int i = 0; i < NPER; ++i) {
+        const int idx = i * 64 + lane;
+        key[i] = idx < total ? i32_ord(top8[(size_t)q * total + idx]) : 0u;
     }
+    int t = kPassAll;
+    if (total >= r) t = max(kPassAll, ord_i32(wave_rth_largest_u32<NPER>(key, r)));
+    if (lane == 0) thr[q] = t;
 }
 
 // exact distances of the listed rows, canonical (distance, position) order, top k; verification of the threshold bet
@@ -1359,7 +1410,7 @@ struct BfScanF32Args {
     const __bf16* q_hi;       // [qpad][128]
     const __bf16* q_lo;
     const float* thr;         // [qpad] pass <=> score >= thr
-    uint32_t* list;           // [qpad][nsplit][2][caph] hit entries: block << 16 | row mask (see hit_mask_f32)
+    uint32_t* list;           // [qpad][caph][nsplit][2] hit entries: block << 16 | row mask (see hit_mask_f32)
     int* list_cnt;            // [qpad][nsplit][2] rows listed
     int n, nqt, nsplit, tps, caph;
     int tile_stride;          // SAMPLE
@@ -1455,7 +1506,7 @@ __global__ __launch_bounds__(256) void bf_scan_f32_kernel(BfScanF32Args a) {
             for (int i = 0; i < 8; ++i) t8[g][i] = -INFINITY;
         } else {
             thr[g] = a.thr[qidx];
-            lp[g] = a.list + (((size_t)qidx * a.nsplit + split) * 2 + h) * a.caph;
+            lp[g] = a.list + (size_t)qidx * a.caph * (2 * a.nsplit) + split * 2 + h;   // entry i of a list: [q][i][list]
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // retire the query loads before any DMA is counted
@@ -1510,7 +1561,7 @@ __global__ __launch_bounds__(256) void bf_scan_f32_kernel(BfScanF32Args a) {
                     if (acc_row(i, h) >= nvalid) km &= ~(0x8000u >> i);
             }
             if (km) {
-                if (ecnt[g] < a.caph) lp[g][ecnt[g]] = ((uint32_t)(row0 - r_begin) >> 5 << 16) | km;
+                if (ecnt[g] < a.caph) lp[g][(size_t)ecnt[g] * (2 * a.nsplit)] = ((uint32_t)(row0 - r_begin) >> 5 << 16) | km;
                 ecnt[g]++;
                 cnt[g] += __builtin_popcount(km);
             }
@@ -1775,7 +1826,7 @@ __global__ __launch_bounds__(NW * 64) void bf_scan_bf16_kernel(BfScanF32Args a) 
             for (int i = 0; i < 8; ++i) t8[g][i] = -INFINITY;
         } else {
             thr[g] = a.thr[qidx];
-            lp[g] = a.list + (((size_t)qidx * a.nsplit + split) * 2 + h) * a.caph;
+            lp[g] = a.list + (size_t)qidx * a.caph * (2 * a.nsplit) + split * 2 + h;   // entry i of a list: [q][i][list]
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1834,7 +1885,7 @@ __global__ __launch_bounds__(NW * 64) void bf_scan_bf16_kernel(BfScanF32Args a) 
                     if (acc_row(i, h) >= nvalid) km &= ~(0x8000u >> i);
             }
             if (km) {
-                if (ecnt[g] < a.caph) lp[g][ecnt[g]] = ((uint32_t)(row0 - r_begin) >> 5 << 16) | km;
+                if (ecnt[g] < a.caph) lp[g][(size_t)ecnt[g] * (2 * a.nsplit)] = ((uint32_t)(row0 - r_begin) >> 5 << 16) | km;
                 ecnt[g]++;
                 cnt[g] += __builtin_popcount(km);
             }
@@ -2106,54 +2157,68 @@ __device__ __forceinline__ float one_product_error(const float* qs, int dim, int
 //          <= s^_r - 1.1 E1 < S_k: the re-rank's proof holds.  If the sample has no such score among its best rcap --
 //          the scores near the top are packed more tightly than the one-product error -- the query's tile is flagged
 //          `precise` and goes through the split-product scan.
-// Only the `depth` best of each lane's eight enter the sort (a lane holds 1/nlists of the sample: more than four of the
+// Only the `depth` best of each lane's eight take part (a lane holds 1/nlists of the sample: more than four of the
 // best rcap in one lane is rare, and a dropped value only lowers a threshold).
+// One wave per query, the sample's values in registers (round 3): s^_r is ONE order statistic (wave_rth_largest_u32), and
+// thr1 -- the first value at least 2.1 E1 below it in descending order -- is the LARGEST such value (the float subtraction is
+// monotone), a masked maximum; its place in the order, which must not exceed rcap, is a count.  Same thresholds, bit for
+// bit, as the sorted array gave.
+template <int NPER>
 __global__ __launch_bounds__(256) void bf_f32_threshold_kernel(const float* top8, int nlists, int depth, int r, int rcap, int nq,
-                                                               const float* queries_sel, int ldb, int dim, float bscale,
+                                                               int qpad, const float* queries_sel, int ldb, int dim, float bscale,
                                                                float bres, int group_q, int force_precise, float* thr3,
                                                                float* thr1, int* precise) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    u64* keys = reinterpret_cast<u64*>(smem);
-    __shared__ float s_qn;
-    const int q = blockIdx.x, tid = threadIdx.x;
+    const int lane = threadIdx.x & 63, q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= qpad) return;
     if (q >= nq) {  // padding queries: nothing passes
-        if (tid == 0) {
+        if (lane == 0) {
             thr3[q] = INFINITY;
             thr1[q] = INFINITY;
         }
         return;
     }
     const int total = nlists * depth;
-    const int P = next_pow2(total < 2 ? 2 : total);
-    for (int i = tid; i < P; i += blockDim.x) {
-        const int l = i / depth, j = i - l * depth;
-        keys[i] = i < total ? (u64)(~f32_ord(top8[((size_t)q * nlists + l) * 8 + j])) : ~0ull;
+    uint32_t key[NPER];
+#pragma unroll
+    for (int i = 0; i < NPER; ++i) {
+        const int idx = i * 64 + lane;
+        const int l = depth == 4 ? idx >> 2 : idx >> 3, j = idx - l * depth;   // (depth is 4 or 8)
+        key[i] = idx < total ? f32_ord(top8[((size_t)q * nlists + l) * 8 + j]) : 0u;
     }
-    if (tid < 64) {
-        const float e1 = one_product_error(queries_sel + (size_t)q * ldb, dim, tid, bscale, bres);
-        if (tid == 0) s_qn = e1;
-    }
-    __syncthreads();
-    block_bitonic_u64_asc(keys, P, tid, blockDim.x);
-    if (tid == 0) {
-        const float t3 = total >= r ? ord_f32(~(uint32_t)keys[r - 1]) : -INFINITY;   // s^_r
-        thr3[q] = t3 - 1.02f * s_qn;
-        float t1 = t3;
-        bool ok = !force_precise;
-        if (ok && t3 > -INFINITY) {
-            const float need = 2.1f * s_qn;
+    const float e1 = one_product_error(queries_sel + (size_t)q * ldb, dim, lane, bscale, bres);
+    const uint32_t T = total >= r ? wave_rth_largest_u32<NPER>(key, r) : 0u;
+    const float t3 = total >= r ? ord_f32(T) : -INFINITY;   // s^_r
+    float t1 = t3;
+    bool ok = !force_precise;
+    if (ok && t3 > -INFINITY) {
+        const float need = 2.1f * e1;
+        uint32_t best = 0u;     // largest key at or below s^_r whose value is at least `need` below it (0: none)
+#pragma unroll
+        for (int i = 0; i < NPER; ++i) {
+            const float v = ord_f32(key[i]);
+            const bool c = key[i] != 0u && key[i] <= T && v > -INFINITY && t3 - v >= need;
+            best = c && key[i] > best ? key[i] : best;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const uint32_t other = (uint32_t)__shfl_xor((int)best, o, 64);
+            best = other > best ? other : best;
+        }
+        ok = false;
+        if (best != 0u) {
+            int above = 0;   // values in front of it in descending order
+#pragma unroll
+            for (int i = 0; i < NPER; ++i) above += __popcll(__builtin_amdgcn_ballot_w64(key[i] > best));
             const int jmax = rcap < total ? rcap : total;
-            ok = false;
-            for (int j = r; j <= jmax; ++j) {
-                const float v = ord_f32(~(uint32_t)keys[j - 1]);
-                if (!(v > -INFINITY)) break;
-                if (t3 - v >= need) {
-                    t1 = v;
-                    ok = true;
-                    break;
-                }
+            const int j = best == T ? r : above + 1;   // (the sorted array's search started at place r)
+            if (j <= jmax) {
+                t1 = ord_f32(best);
+                ok = true;
             }
         }
+    }
+    if (lane == 0) {
+        thr3[q] = t3 - 1.02f * e1;
         thr1[q] = t1;
         if (!ok) atomicOr(&precise[q / group_q], 1);
     }
@@ -2180,13 +2245,19 @@ struct RerankListF32Args {
     int no_split;              // rows longer than 128: no split-product scan -- a `precise` tile goes to the adaptive kernel
     float bmax;                // largest row norm of the selection rows
     float bres;                // largest bf16 rounding residual of the selection rows (see row_maxnorm_kernel)
+    unsigned long long* prof;  // NMSLIB_GPU_DEBUG & 4096: phase clocks (100 MHz), summed over the workgroups
 };
 
 __global__ __launch_bounds__(256) void bf_rerank_f32_list_kernel(RerankListF32Args a) {
+    const unsigned long long t0 = a.prof ? wall_clock64() : 0;
+    auto lap = [&](int i) __attribute__((always_inline)) {
+        if (a.prof && threadIdx.x == 0) atomicAdd(&a.prof[i], wall_clock64() - t0);
+    };
     extern __shared__ __attribute__((aligned(16))) char smem[];
     u64* keys = reinterpret_cast<u64*>(smem);              // [p2max]
     int* offs = reinterpret_cast<int*>(keys + a.p2max);    // [2 * nsplit + 1]
-    __shared__ int s_over;
+    __shared__ int s_over, s_split;
+    __shared__ float s_qn2, s_e1, s_thr;
     const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nl = 2 * a.nsplit;
     // exclusive prefix sum of the (clipped) list lengths: wave 0, each lane a run of consecutive lists
@@ -2220,6 +2291,21 @@ __global__ __launch_bounds__(256) void bf_rerank_f32_list_kernel(RerankListF32Ar
         }
         if (tid == 63) offs[nl] = incl;
         if (__any(over != 0) && tid == 0) s_over = 1;
+    } else if (wave == 1) {
+        // what the proof at the end needs of the query alone (its norm, the error bound of its tile's scan, its threshold):
+        // requested here, beside the list lengths, instead of as three more memory round trips behind the sort
+        const bool split_product = a.precise[q / a.fail_queries] != 0;
+        const float* qs = a.queries_sel + (size_t)q * a.ldb;
+        float ss = 0.f;
+        for (int d = lane; d < a.dim; d += 64) ss = fmaf(qs[d], qs[d], ss);
+        ss = wave_sum(ss);
+        const float e1 = split_product ? 0.f : one_product_error(qs, a.dim, lane, a.space == SP_L2 || a.space == SP_NEGDOT ? a.bmax : 1.0f, a.bres);
+        if (lane == 0) {
+            s_qn2 = ss;
+            s_e1 = e1;
+            s_split = split_product ? 1 : 0;
+            s_thr = split_product ? a.thr[q] : a.thr1[q];
+        }
     }
     __syncthreads();
     const int total = offs[nl];
@@ -2234,9 +2320,16 @@ __global__ __launch_bounds__(256) void bf_rerank_f32_list_kernel(RerankListF32Ar
         if (tid == 0) atomicOr(&a.tile_fail[q / a.fail_queries], 1);
         return;
     }
+    lap(0);
     scan_gather_entries(keys, offs, a.list, q, nl, a.caph, a.tps, tid, blockDim.x);
     __syncthreads();
+    lap(1);
     const int P = next_pow2(total < 2 ? 2 : total);
+    if (a.prof && tid == 0) {
+        atomicAdd(&a.prof[8], (unsigned long long)total);
+        atomicAdd(&a.prof[9], (unsigned long long)P);
+        atomicAdd(&a.prof[10], 1ull);
+    }
     // exact distances: 16 lanes per row, 4 rows per wave and pass, 4 passes requested together -- 64 rows of the query
     // in flight per workgroup round (the kernel is a chain of memory round trips).  Bit-identical to
     // wave_exact_distance_f32 (the adaptive path's re-rank; a query must get the same floats whichever path served it):
@@ -2380,9 +2473,37 @@ __global__ __launch_bounds__(256) void bf_rerank_f32_list_kernel(RerankListF32Ar
             }
         }
     }
-    for (int i = total + tid; i < P; i += blockDim.x) keys[i] = ~0ull;
     __syncthreads();
-    block_bitonic_u64_asc(keys, P, tid, blockDim.x);
+    lap(2);
+    if (total <= 512 && a.k <= 32) {
+        // the first k of the order without sorting everything: every wave sorts a quarter (128 keys, two per lane, in
+        // registers), the four heads of 32 meet in LDS and wave 0 sorts those -- two barriers instead of the 45 of the
+        // workgroup-wide bitonic sort of 512 keys
+        __shared__ u64 s_head[128];
+        const int e0 = wave * 128 + 2 * lane;
+        u64 k0 = e0 < total ? keys[e0] : ~0ull, k1 = e0 + 1 < total ? keys[e0 + 1] : ~0ull;
+        wave_sort128_u64(k0, k1, lane);
+        if (lane < 16) {
+            s_head[wave * 32 + 2 * lane] = k0;
+            s_head[wave * 32 + 2 * lane + 1] = k1;
+        }
+        __syncthreads();
+        if (wave == 0) {
+            k0 = s_head[2 * lane];
+            k1 = s_head[2 * lane + 1];
+            wave_sort128_u64(k0, k1, lane);
+            if (lane < 16) {
+                keys[2 * lane] = k0;
+                keys[2 * lane + 1] = k1;
+            }
+        }
+        __syncthreads();
+    } else {
+        for (int i = total + tid; i < P; i += blockDim.x) keys[i] = ~0ull;
+        __syncthreads();
+        block_bitonic_u64_asc(keys, P, tid, blockDim.x);
+    }
+    lap(3);
     const int found = total < a.k ? total : a.k;
     // PROOF that no unlisted row belongs to the top k.  The selection score of every row carries an error of at most
     // E = 2^-14 |q||b|: bf16 rounds to 8 significant bits (relative error <= 2^-8), so the dropped lo.lo product and the
@@ -2391,20 +2512,7 @@ __global__ __launch_bounds__(256) void bf_rerank_f32_list_kernel(RerankListF32Ar
     // their exact score is below T + E; if the exact score S_k of the k-th result is at least that, every unlisted row
     // is strictly farther than the k-th result.  Otherwise the adaptive kernel redoes the query's tile group.
     if (total < a.n) {
-        __shared__ float s_qn2, s_e1;
-        const bool split_product = a.precise[q / a.fail_queries] != 0;
-        if (tid < 64) {
-            const float* qs = a.queries_sel + (size_t)q * a.ldb;
-            float ss = 0.f;
-            for (int d = tid; d < a.dim; d += 64) ss = fmaf(qs[d], qs[d], ss);
-            ss = wave_sum(ss);
-            const float e1 = split_product ? 0.f : one_product_error(qs, a.dim, tid, a.space == SP_L2 || a.space == SP_NEGDOT ? a.bmax : 1.0f, a.bres);
-            if (tid == 0) {
-                s_qn2 = ss;
-                s_e1 = e1;
-            }
-        }
-        __syncthreads();
+        const bool split_product = s_split != 0;
         if (tid == 0) {
             const float qn2 = s_qn2, qn = sqrtf(qn2);
             const float dk = ord_f32((uint32_t)(keys[found - 1] >> 32));
@@ -2419,12 +2527,13 @@ __global__ __launch_bounds__(256) void bf_rerank_f32_list_kernel(RerankListF32Ar
                 sk = (a.space == SP_ANGULAR ? cosf(dk) : 1.0f - dk) * qn;
                 e = 6.1036e-5f * qn;
             }
-            const float t = split_product ? a.thr[q] : a.thr1[q];
+            const float t = s_thr;
             if (!split_product) e = s_e1;   // one bf16 product
             e += 1e-6f * (fabsf(sk) + fabsf(t));  // rounding of sk itself
             if (!(sk - t >= e)) atomicOr(&a.tile_fail[q / a.fail_queries], 1);
         }
     }
+    lap(4);
     for (int i = tid; i < a.k; i += blockDim.x) {
         int32_t id = -1;
         float d = INFINITY;
@@ -2438,6 +2547,7 @@ __global__ __launch_bounds__(256) void bf_rerank_f32_list_kernel(RerankListF32Ar
         a.out_dists[(size_t)q * a.k + i] = d;
     }
     if (tid == 0 && a.out_cnt) a.out_cnt[q] = found;
+    lap(5);
 }
 
 // largest row norm -> out[0]; largest bf16 rounding residual |b - bf16(b)| -> out[1] (relative to |b| if `relative`: the
@@ -3272,10 +3382,12 @@ hipError_t launch_bf_u8_fast(const BfU8Fast& f, int n, int nq, int k, const uint
         e = hipGetLastError();
     }
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(bf_u8_threshold_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)f.lds_thr);
+    if (2 * f.s_nsplit * 8 <= 512)
+        hipLaunchKernelGGL(bf_u8_threshold_kernel<8>, dim3((f.qpad + 3) / 4), dim3(256), 0, s, top8, 2 * f.s_nsplit, f.r, nq, f.qpad, thr);
+    else   // (s_nsplit <= 64: at most 1024 sample values per query)
+        hipLaunchKernelGGL(bf_u8_threshold_kernel<16>, dim3((f.qpad + 3) / 4), dim3(256), 0, s, top8, 2 * f.s_nsplit, f.r, nq, f.qpad, thr);
+    e = hipGetLastError();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(bf_u8_threshold_kernel, dim3(f.qpad), dim3(256), f.lds_thr, s, top8, 2 * f.s_nsplit, f.r, nq, thr);
     e = hipMemsetAsync(tile_fail, 0, (size_t)f.nqt * 4, s);
     if (e != hipSuccess) return e;
     // 2. scan with fixed thresholds
@@ -3512,13 +3624,16 @@ hipError_t launch_bf_f32_fast(const BfF32Fast& f, int space, int n, int dim, int
     e = scan(sa, true, 1, 8 * sa.nqt * (f.s_nsplit / 8));
     if (e != hipSuccess) return e;
     // (fallback flags + precise flags: cleared by the prep kernel)
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(bf_f32_threshold_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)f.lds_thr);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(bf_f32_threshold_kernel, dim3(f.qpad), dim3(256), f.lds_thr, s, top8, 2 * f.s_nsplit,
-                       f.rcap <= 64 && f.s_nsplit >= 32 ? 4 : 8, f.r, f.rcap, nq,
-                       queries_sel, ldb, dim, f.mode == 2 ? 1.0f : bmax, bres, f.tq, f.force_precise ? 1 : 0, thr,
-                       thr1, precise);
+    {
+        const int depth = f.rcap <= 64 && f.s_nsplit >= 32 ? 4 : 8;
+        const dim3 tgrid((f.qpad + 3) / 4);
+#define BF_THR_ARGS                                                                                                               \
+    top8, 2 * f.s_nsplit, depth, f.r, f.rcap, nq, f.qpad, queries_sel, ldb, dim, f.mode == 2 ? 1.0f : bmax, bres, f.tq,           \
+        f.force_precise ? 1 : 0, thr, thr1, precise
+        if (2 * f.s_nsplit * depth <= 512) hipLaunchKernelGGL(bf_f32_threshold_kernel<8>, tgrid, dim3(256), 0, s, BF_THR_ARGS);
+        else hipLaunchKernelGGL(bf_f32_threshold_kernel<16>, tgrid, dim3(256), 0, s, BF_THR_ARGS);   // (s_nsplit <= 64)
+#undef BF_THR_ARGS
+    }
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     // 2. scan with fixed thresholds: every query tile by one of the two kernels (the other's workgroups leave at once)
@@ -3570,12 +3685,28 @@ hipError_t launch_bf_f32_fast(const BfF32Fast& f, int space, int n, int dim, int
     r.precise = precise;
     r.bmax = bmax;
     r.bres = bres;
+    static const int dbg_prof = getenv("NMSLIB_GPU_DEBUG") ? atoi(getenv("NMSLIB_GPU_DEBUG")) : 0;
+    static unsigned long long* d_prof = nullptr;
+    if (dbg_prof & 4096) {
+        if (!d_prof) (void)hipMalloc(&d_prof, 16 * 8);
+        (void)hipMemsetAsync(d_prof, 0, 16 * 8, s);
+        r.prof = d_prof;
+    }
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(bf_rerank_f32_list_kernel),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)f.lds_rerank);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(bf_rerank_f32_list_kernel, dim3(nq), dim3(256), f.lds_rerank, s, r);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
+    if (dbg_prof & 4096) {
+        unsigned long long h[16];
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpy(h, d_prof, sizeof(h), hipMemcpyDeviceToHost);
+        const double wg = h[10] ? (double)h[10] : 1.0;
+        fprintf(stderr, "[rerank f32 list] workgroups %llu rows/query %.1f P %.1f | us since start: prefix %.2f gather %.2f distances %.2f "
+                "sort %.2f proof %.2f out %.2f\n", h[10], h[8] / wg, h[9] / wg, h[0] / wg / 100, h[1] / wg / 100, h[2] / wg / 100,
+                h[3] / wg / 100, h[4] / wg / 100, h[5] / wg / 100);
+    }
     {   // NMSLIB_GPU_DEBUG & 2048: checksums of the intermediate buffers of this batch (determinism screens)
         static const int dbg = getenv("NMSLIB_GPU_DEBUG") ? atoi(getenv("NMSLIB_GPU_DEBUG")) : 0;
         if (dbg & 2048) {
@@ -3593,11 +3724,12 @@ hipError_t launch_bf_f32_fast(const BfF32Fast& f, int space, int n, int dim, int
             (void)hipMemcpy(lst.data(), list, lst.size() * 4, hipMemcpyDeviceToHost);
             unsigned long long lx = 1469598103934665603ull;   // only the entries that exist
             long long rows = 0;
+            const size_t nl = (size_t)f.nsplit * 2;
             for (size_t i = 0; i < cnt.size(); ++i) {
                 rows += cnt[i];
                 int have = 0;
                 for (int j = 0; j < f.caph && have < cnt[i]; ++j) {
-                    const uint32_t e = lst[i * f.caph + j];
+                    const uint32_t e = lst[((i / nl) * f.caph + j) * nl + i % nl];
                     lx = (lx ^ e) * 1099511628211ull;
                     have += __builtin_popcount(e & 0xffffu);
                 }
