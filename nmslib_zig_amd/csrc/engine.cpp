@@ -742,6 +742,7 @@ void Engine::finalize() {
                     mu2 += m * m;
                 }
                 const double spread2 = std::max(0.0, st[(size_t)ldb_] / (double)n - mu2);
+                cosc_spread2_ = spread2;
                 bool centre = mu2 > 0.0625 * spread2;
                 if (const char* env = getenv("NMSLIB_GPU_CENTER")) centre = atoi(env) != 0;
                 if (centre) {
@@ -786,8 +787,46 @@ void Engine::finalize() {
             d_bf_hi_.release();
             d_bf_lo_.release();
             d_auxp_.release();
-            const bool fast_space = space_ == SP_L2 || space_ == SP_NEGDOT ||
-                                    ((space_ == SP_COSINE || space_ == SP_ANGULAR) && !centred_);
+            const bool cosine_space = space_ == SP_COSINE || space_ == SP_ANGULAR;
+            const bool fast_space = space_ == SP_L2 || space_ == SP_NEGDOT || (cosine_space && !centred_);
+            if (cosine_space && centred_ && dim_ + 3 <= 1024 && n >= 65536) {
+                // centred cosine / angular (round 3): the score -(1 - cos)|q| as an inner product of rows and queries with
+                // three more columns (bf_kernels.hip, row_aug_cosc_kernel); bf16 tiles of those rows, scanned in the
+                // inner-product mode.  A zero-norm row has no score of this form: the index then stays on the adaptive kernel.
+                const BfF32Fast f0 = bf_f32_fast_plan((int)n, (int)dim_, 1024, 10, space_, true);
+                if (f0.use) {
+                    const size_t dp = (size_t)f0.dp;
+                    const size_t n_pad = (size_t)bf_f32_rows_padded((int)n);
+                    DevBuf d_aug, d_flag;
+                    d_aug.ensure(n * dp * 4);
+                    d_flag.ensure(16);
+                    hip_check(hipMemsetAsync(d_flag.ptr(), 0, 16, stream_), "clear");
+                    // (the two constant columns balanced at the typical (|b'|^2 - db^2) / 2 <= spread^2 / 2)
+                    cosc_lambda_ = (float)std::sqrt(std::max(0.5 * cosc_spread2_, 1e-30));
+                    hip_check(launch_row_aug_cosc(d_rows_.as<float>(), sel_rows, (int)n, ldb_, (int)dim_, mu_norm_, cosc_lambda_,
+                                                  d_aug.as<float>(), (int)dp, d_flag.as<int>(), stream_),
+                              "augmented rows");
+                    hip_check(launch_row_maxnorm(d_aug.as<float>(), (int)n, (int)dp, (int)dim_ + 3, false, d_flag.as<float>() + 1,
+                                                 stream_),
+                              "augmented row norms");
+                    int fl[3] = {0, 0, 0};
+                    hip_check(hipMemcpyAsync(fl, d_flag.ptr(), 12, hipMemcpyDeviceToHost, stream_), "flags");
+                    hip_check(hipStreamSynchronize(stream_), "augmented rows");
+                    if (fl[0] == 0) {
+                        std::memcpy(&bmax_c_, &fl[1], 4);
+                        std::memcpy(&bres_c_, &fl[2], 4);
+                        d_bf_hi_.ensure(n_pad * dp * 2);
+                        if (dp == 128) d_bf_lo_.ensure(n_pad * 128 * 2);
+                        d_auxp_.ensure(n_pad * 4);
+                        hip_check(launch_split_bf16(d_aug.as<float>(), (int)n, (int)n_pad, (int)dp, (int)dim_ + 3, d_bf_hi_.ptr(),
+                                                    dp == 128 ? d_bf_lo_.ptr() : nullptr, nullptr, 0.f, d_auxp_.as<float>(),
+                                                    stream_, (int)dp),
+                                  "split rows");
+                        hip_check(hipStreamSynchronize(stream_), "split rows");   // (d_aug goes out of scope)
+                        have_bf16_ = true;
+                    }
+                }
+            }
             if (fast_space && dim_ <= 1024 && n >= 65536) {
                 // (rows up to 128 dimensions: hi and lo tiles; longer rows, round 3: hi tiles of 128 * kch columns
                 //  for the K-chunked one-product scan -- the plan's kch, which depends on the dimension only)
@@ -1090,6 +1129,17 @@ void Engine::knn_brute(const void* d_queries, size_t nq, size_t k, int32_t* d_id
                           "centre queries");
                 qsel = ws_qsel_.as<float>();
             }
+            if (f.cosc) {   // centred cosine / angular: the augmented queries (query_aug_cosc_kernel) are what the scans see
+                ws_qaux_.ensure((size_t)f.qpad * 16);
+                ws_qaug_.ensure((size_t)f.qpad * f.dp * 4);
+                hip_check(launch_query_aux_cosc(ws_qpad_.as<float>(), ws_qsel_.as<float>(), f.qpad, ldb, dim_eff, mu_norm_,
+                                                ws_qaux_.as<float>(), stream),
+                          "query aux");
+                hip_check(launch_query_aug_cosc(ws_qsel_.as<float>(), ws_qaux_.as<float>(), (int)nq, f.qpad, ldb, dim_eff,
+                                                cosc_lambda_, ws_qaug_.as<float>(), f.dp, stream),
+                          "augmented queries");
+                qsel = ws_qaug_.as<float>();
+            }
             ws_cand_.ensure(bf_cand_elems(f.fallback) * 8);
             ws_cnt_.ensure(bf_cnt_elems(f.fallback) * 4);
             ws_f32_q_.ensure((size_t)f.qpad * f.dp * 2 * 2);
@@ -1110,11 +1160,13 @@ void Engine::knn_brute(const void* d_queries, size_t nq, size_t k, int32_t* d_id
             }
             hip_check(launch_bf_f32_fast(f, space_, (int)d_n_, dim_eff, ldb, (int)nq, (int)k, d_rows_.as<float>(),
                                          centred_ ? d_rows_sel_.as<float>() : d_rows_.as<float>(), d_aux_.as<float>(),
-                                         d_bf_hi_.ptr(), d_bf_lo_.ptr(), d_auxp_.as<float>(), bmax_, bres_, ws_qpad_.as<float>(), qsel, qh, ql,
+                                         d_bf_hi_.ptr(), d_bf_lo_.ptr(), d_auxp_.as<float>(), f.cosc ? bmax_c_ : bmax_,
+                                         f.cosc ? bres_c_ : bres_, ws_qpad_.as<float>(), qsel, qh, ql,
                                          ws_u8_cand_.as<float>(), ws_cand_.as<unsigned long long>(), ws_cnt_.as<int>(), thr,
                                          ws_u8_list_.as<uint32_t>(), ws_u8_listcnt_.as<int>(), tile_fail, ws_flags_.as<int>(),
                                          d_ids_.as<int32_t>(), d_ids, d_dists, d_cnt, eb, ee, stream,
-                                         centred_ ? nullptr : static_cast<const float*>(d_queries), centred_ ? nullptr : ws_qpad_.as<float>()),
+                                         centred_ ? nullptr : static_cast<const float*>(d_queries), centred_ ? nullptr : ws_qpad_.as<float>(),
+                                         f.cosc ? ws_qaux_.as<float>() : nullptr, f.cosc ? ws_qsel_.as<float>() : nullptr, f.dp),
                       "bf_f32_fast");
             last_path = 1;
             fast_flags_ = tile_fail;

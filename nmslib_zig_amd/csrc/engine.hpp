@@ -251,6 +251,10 @@ class Engine {
     DevBuf d_rows_sel_, d_mean_;  // brute-force L2 on un-centred data: selection copy (rows - column mean) and the mean
     bool centred_ = false;
     double mu_norm_ = 0;  // |column mean| (centred cosine scoring)
+    double cosc_spread2_ = 0;          // E|b - mean|^2 measured at finalize
+    float cosc_lambda_ = 1.f;          // centred cosine on the fast path: scale of the two constant columns (row_aug_cosc_kernel)
+    float bmax_c_ = 0, bres_c_ = 0;    // largest norm / bf16 rounding residual of the augmented rows
+    DevBuf ws_qaug_;                   // augmented queries of a batch
     size_t d_n_ = 0;
     int ldb_ = 0;
     HnswDeviceGraph dg_{};

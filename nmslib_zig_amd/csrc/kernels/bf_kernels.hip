@@ -2245,6 +2245,8 @@ struct RerankListF32Args {
     int no_split;              // rows longer than 128: no split-product scan -- a `precise` tile goes to the adaptive kernel
     float bmax;                // largest row norm of the selection rows
     float bres;                // largest bf16 rounding residual of the selection rows (see row_maxnorm_kernel)
+    int sel_dim, sel_ld;       // columns / row stride of queries_sel (dim / ldb, or the augmented queries' when qaux is set)
+    const float* qaux;         // centred cosine / angular: [qpad][4] = |q'|^2, |q| - |mu|, |q|, flag (0: zero-norm query); else null
     unsigned long long* prof;  // NMSLIB_GPU_DEBUG & 4096: phase clocks (100 MHz), summed over the workgroups
 };
 
@@ -2295,11 +2297,11 @@ __global__ __launch_bounds__(256) void bf_rerank_f32_list_kernel(RerankListF32Ar
         // what the proof at the end needs of the query alone (its norm, the error bound of its tile's scan, its threshold):
         // requested here, beside the list lengths, instead of as three more memory round trips behind the sort
         const bool split_product = a.precise[q / a.fail_queries] != 0;
-        const float* qs = a.queries_sel + (size_t)q * a.ldb;
+        const float* qs = a.queries_sel + (size_t)q * a.sel_ld;
         float ss = 0.f;
-        for (int d = lane; d < a.dim; d += 64) ss = fmaf(qs[d], qs[d], ss);
+        for (int d = lane; d < a.sel_dim; d += 64) ss = fmaf(qs[d], qs[d], ss);
         ss = wave_sum(ss);
-        const float e1 = split_product ? 0.f : one_product_error(qs, a.dim, lane, a.space == SP_L2 || a.space == SP_NEGDOT ? a.bmax : 1.0f, a.bres);
+        const float e1 = split_product ? 0.f : one_product_error(qs, a.sel_dim, lane, a.space == SP_L2 || a.space == SP_NEGDOT || a.qaux ? a.bmax : 1.0f, a.bres);
         if (lane == 0) {
             s_qn2 = ss;
             s_e1 = e1;
@@ -2309,7 +2311,8 @@ __global__ __launch_bounds__(256) void bf_rerank_f32_list_kernel(RerankListF32Ar
     }
     __syncthreads();
     const int total = offs[nl];
-    if (a.no_split && a.precise[q / a.fail_queries] != 0) {   // (no scan served this tile: its lists are stale)
+    if ((a.no_split && a.precise[q / a.fail_queries] != 0) ||      // (no scan served this tile: its lists are stale)
+        (a.qaux && a.qaux[(size_t)q * 4 + 3] == 0.f)) {            // (zero-norm query, centred cosine: every distance is 1)
         if (tid == 0) atomicOr(&a.tile_fail[q / a.fail_queries], 1);
         return;
     }
@@ -2516,8 +2519,19 @@ __global__ __launch_bounds__(256) void bf_rerank_f32_list_kernel(RerankListF32Ar
         if (tid == 0) {
             const float qn2 = s_qn2, qn = sqrtf(qn2);
             const float dk = ord_f32((uint32_t)(keys[found - 1] >> 32));
-            float sk, e;
-            if (a.space == SP_L2) {
+            float sk, e, extra = 0.f;
+            if (a.qaux) {
+                // centred cosine / angular: the score is -(1 - cos)|q|, the inner product of the augmented vectors (qn, bmax:
+                // theirs).  Beyond the scan's error: the f32 rounding of the augmented columns (2^-22 of the sum of the
+                // products' magnitudes) and of the reference formula itself -- its similarity carries a few ulp of 1.0, and the
+                // proof is about the distances the reference computes: 2e-6 |q| in score units.
+                const float sh = sinf(0.5f * dk);
+                const float omc = a.space == SP_ANGULAR ? 2.0f * sh * sh : dk;
+                const float qnorm = a.qaux[(size_t)q * 4 + 2];
+                sk = -omc * qnorm;
+                e = 6.1036e-5f * qn * a.bmax;
+                extra = 1e-6f * qn * a.bmax + 2e-6f * qnorm;
+            } else if (a.space == SP_L2) {
                 sk = 0.5f * (qn2 - dk * dk);
                 e = 6.1036e-5f * qn * a.bmax;
             } else if (a.space == SP_NEGDOT) {
@@ -2529,7 +2543,7 @@ __global__ __launch_bounds__(256) void bf_rerank_f32_list_kernel(RerankListF32Ar
             }
             const float t = s_thr;
             if (!split_product) e = s_e1;   // one bf16 product
-            e += 1e-6f * (fabsf(sk) + fabsf(t));  // rounding of sk itself
+            e += extra + 1e-6f * (fabsf(sk) + fabsf(t));  // rounding of sk itself
             if (!(sk - t >= e)) atomicOr(&a.tile_fail[q / a.fail_queries], 1);
         }
     }
@@ -2880,6 +2894,70 @@ __global__ void query_aux_cosc_kernel(const float* orig, const float* centred, i
         qaux[(size_t)q * 4 + 1] = (float)(nn - mu_norm);
         qaux[(size_t)q * 4 + 2] = (float)nn;
         qaux[(size_t)q * 4 + 3] = zero ? 0.f : 1.f;
+    }
+}
+
+// Centred cosine / angular on the bf16 fast path (round 3).  The BF_COSC score -(1 - cos)|q| (see bf_select_f32_kernel)
+// is an INNER PRODUCT of augmented vectors -- three more columns behind the centred ones:
+//     -(1 - cos(q,b)) |q| = [ q'.b' - dq db - (|b'|^2 - db^2)/2 - (|q'|^2 - dq^2)/2 ] / |b|,   dq = |q| - |mu|, db = |b| - |mu|
+//     q+ = ( q',  -dq,  lambda,          -cq / lambda ),      cq = (|q'|^2 - dq^2) / 2
+//     b+ = ( b',   db,  -cb / lambda,     lambda      ) / |b|, cb = (|b'|^2 - db^2) / 2
+// so the one-product / split-product scans run it in their inner-product mode (no start values) over rows of dim + 3
+// columns.  lambda ~ sqrt(cb) balances the two constant columns: the error bounds are Cauchy-Schwarz bounds over the whole
+// vector, and a column pair (1, c) with c ~ 10^4 would inflate them by that factor.  Norms in f64 as in row_aux_cosc_kernel.
+__global__ void row_aug_cosc_kernel(const float* orig, const float* centred, int n, int ldb, int dim, double mu_norm,
+                                    float lambda, float* out, int ldo, int* zero_rows) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= n) return;
+    const float* p = orig + (size_t)row * ldb;
+    const float* c = centred + (size_t)row * ldb;
+    double nb2 = 0.0, a = 0.0;
+    float nf = 0.f;
+    for (int d = lane; d < dim; d += 64) {
+        const float x = p[d], y = c[d];
+        nb2 += (double)x * (double)x;
+        a += (double)y * (double)y;
+        nf = fmaf(x, x, nf);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        nb2 += __shfl_xor(nb2, o, 64);
+        a += __shfl_xor(a, o, 64);
+    }
+    nf = wave_sum(nf);
+    const bool zero = nf < 1.17549435e-38f * 2.0f;   // (the test of row_aux_cosc_kernel)
+    const double nb = sqrt(nb2), db = nb - mu_norm, cb = 0.5 * (a - db * db), inv = zero ? 0.0 : 1.0 / nb;
+    float* o = out + (size_t)row * ldo;
+    for (int d = lane; d < ldo; d += 64) {
+        double v = 0.0;
+        if (d < dim) v = (double)c[d] * inv;
+        else if (d == dim) v = db * inv;
+        else if (d == dim + 1) v = -cb / (double)lambda * inv;
+        else if (d == dim + 2) v = (double)lambda * inv;
+        o[d] = (float)v;
+    }
+    if (zero && lane == 0) atomicOr(zero_rows, 1);   // (no score of this form for a zero row: the caller keeps the adaptive path)
+}
+// q+ of every (padded) query from its centred copy and qaux = {|q'|^2, |q| - |mu|, |q|, flag} (query_aux_cosc_kernel)
+__global__ void query_aug_cosc_kernel(const float* centred, const float* qaux, int nq, int qpad, int ldb, int dim, float lambda,
+                                      float* out, int ldo) {
+    const int lane = threadIdx.x & 63;
+    const int q = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (q >= qpad) return;
+    float* o = out + (size_t)q * ldo;
+    const bool real = q < nq;
+    const double a = real ? (double)qaux[(size_t)q * 4 + 0] : 0.0, dq = real ? (double)qaux[(size_t)q * 4 + 1] : 0.0;
+    const double cq = 0.5 * (a - dq * dq);
+    for (int d = lane; d < ldo; d += 64) {
+        float v = 0.f;
+        if (real) {
+            if (d < dim) v = centred[(size_t)q * ldb + d];
+            else if (d == dim) v = (float)-dq;
+            else if (d == dim + 1) v = lambda;
+            else if (d == dim + 2) v = (float)(-cq / (double)lambda);
+        }
+        o[d] = v;
     }
 }
 
@@ -3442,11 +3520,19 @@ hipError_t launch_bf_u8_fast(const BfU8Fast& f, int n, int nq, int k, const uint
 // ---- f32 fast path (see bf_scan_f32_kernel) -----------------------------------------------------------------
 BfF32Fast bf_f32_fast_plan(int n, int dim, int nq, int k, int space, bool cosine_centred) {
     BfF32Fast f{};
-    const bool space_ok = space == SP_L2 || space == SP_NEGDOT || ((space == SP_COSINE || space == SP_ANGULAR) && !cosine_centred);
+    const bool cosine = space == SP_COSINE || space == SP_ANGULAR;
+    const bool space_ok = space == SP_L2 || space == SP_NEGDOT || cosine;
+    // centred cosine / angular (round 3): the inner-product mode over rows of dim + 3 columns (row_aug_cosc_kernel)
+    f.cosc = cosine && cosine_centred;
+    const int dim_rows = dim;
+    if (f.cosc) dim += 3;
     f.use = space_ok && dim <= 1024 && n >= 65536 && nq >= 256 && k <= 128;
     if (const char* e = getenv("NMSLIB_GPU_F32_FAST")) f.use = f.use && atoi(e) != 0;
+    if (f.cosc)
+        if (const char* e = getenv("NMSLIB_GPU_COSC_FAST")) f.use = f.use && atoi(e) != 0;
     if (!f.use) return f;
-    f.mode = space == SP_L2 ? 0 : (space == SP_NEGDOT ? 1 : 2);
+    f.mode = space == SP_L2 ? 0 : ((space == SP_NEGDOT || f.cosc) ? 1 : 2);
+    f.sel_dim = dim;
     // rows longer than 128 (round 3): chunks of 128 dimensions (bf_scan_bf16_kernel<.., KCH>), instantiated for 2, 3, 4, 6, 8
     f.kch = dim <= 128 ? 1 : (dim <= 256 ? 2 : (dim <= 384 ? 3 : (dim <= 512 ? 4 : (dim <= 768 ? 6 : 8))));
     f.dp = 128 * f.kch;
@@ -3498,7 +3584,7 @@ BfF32Fast bf_f32_fast_plan(int n, int dim, int nq, int k, int space, bool cosine
     f.s_nsplit = nss;
     f.s_tps = (stiles + nss - 1) / nss;
     f.lds_thr = (size_t)host_next_pow2(nss * 2 * 8) * 8 + 16;
-    f.fallback = bf_make_plan(n, dim, nq, k, false, tq);
+    f.fallback = bf_make_plan(n, dim_rows, nq, k, false, tq);
     if (f.kch > 1) f.force_precise = false;   // (no split-product scan at these lengths: such tiles go to the adaptive kernel)
     return f;
 }
@@ -3583,7 +3669,11 @@ hipError_t launch_bf_f32_fast(const BfF32Fast& f, int space, int n, int dim, int
                               void* q_hi, void* q_lo, float* top8, unsigned long long* cand_fb, int* cnt_fb, float* thr,
                               uint32_t* list, int* list_cnt, int* tile_fail, int* flags_fb, const int32_t* ext_ids,
                               int32_t* out_ids, float* out_dists, int32_t* out_cnt, hipEvent_t scan_begin,
-                              hipEvent_t scan_end, hipStream_t s, const float* queries_raw, float* queries_pad_out) {
+                              hipEvent_t scan_end, hipStream_t s, const float* queries_raw, float* queries_pad_out,
+                              const float* qaux_cosc, const float* queries_centred, int sel_ld) {
+    // centred cosine / angular (f.cosc): queries_sel holds the augmented queries q+ [qpad][sel_ld] of f.sel_dim columns and
+    // base_hi / base_lo the augmented rows (bmax / bres: theirs); queries_centred + qaux_cosc serve the adaptive fallback
+    const int sdim = f.cosc ? f.sel_dim : dim, sld = f.cosc ? sel_ld : ldb;
     float* thr1 = thr + f.qpad;
     int* precise = tile_fail + f.nqt;
     hipError_t e;
@@ -3594,8 +3684,8 @@ hipError_t launch_bf_f32_fast(const BfF32Fast& f, int space, int n, int dim, int
         size_t work = (size_t)f.qpad * f.dp > gwords ? (size_t)f.qpad * f.dp : gwords;
         size_t grid = (work + 255) / 256;
         if (grid > 2048) grid = 2048;
-        hipLaunchKernelGGL(bf_f32_prep_kernel, dim3((unsigned)grid), dim3(256), 0, s, queries_raw, nq, dim, queries_sel, f.qpad,
-                           ldb, queries_pad_out, static_cast<__bf16*>(q_hi), f.kch > 1 ? nullptr : static_cast<__bf16*>(q_lo),
+        hipLaunchKernelGGL(bf_f32_prep_kernel, dim3((unsigned)grid), dim3(256), 0, s, queries_raw, nq, sdim, queries_sel, f.qpad,
+                           sld, queries_pad_out, static_cast<__bf16*>(q_hi), f.kch > 1 ? nullptr : static_cast<__bf16*>(q_lo),
                            tile_fail, 2 * f.nqt, flags_fb, fb.nqt, gthr, gwords, f.dp);
         e = hipGetLastError();
         if (e != hipSuccess) return e;
@@ -3628,7 +3718,7 @@ hipError_t launch_bf_f32_fast(const BfF32Fast& f, int space, int n, int dim, int
         const int depth = f.rcap <= 64 && f.s_nsplit >= 32 ? 4 : 8;
         const dim3 tgrid((f.qpad + 3) / 4);
 #define BF_THR_ARGS                                                                                                               \
-    top8, 2 * f.s_nsplit, depth, f.r, f.rcap, nq, f.qpad, queries_sel, ldb, dim, f.mode == 2 ? 1.0f : bmax, bres, f.tq,           \
+    top8, 2 * f.s_nsplit, depth, f.r, f.rcap, nq, f.qpad, queries_sel, sld, sdim, f.mode == 2 ? 1.0f : bmax, bres, f.tq,          \
         f.force_precise ? 1 : 0, thr, thr1, precise
         if (2 * f.s_nsplit * depth <= 512) hipLaunchKernelGGL(bf_f32_threshold_kernel<8>, tgrid, dim3(256), 0, s, BF_THR_ARGS);
         else hipLaunchKernelGGL(bf_f32_threshold_kernel<16>, tgrid, dim3(256), 0, s, BF_THR_ARGS);   // (s_nsplit <= 64)
@@ -3680,6 +3770,9 @@ hipError_t launch_bf_f32_fast(const BfF32Fast& f, int space, int n, int dim, int
     r.dim = dim;
     r.ldb = ldb;
     r.queries_sel = queries_sel;
+    r.sel_dim = sdim;
+    r.sel_ld = sld;
+    r.qaux = f.cosc ? qaux_cosc : nullptr;
     r.thr = thr;
     r.thr1 = thr1;
     r.precise = precise;
@@ -3741,7 +3834,8 @@ hipError_t launch_bf_f32_fast(const BfF32Fast& f, int space, int n, int dim, int
     }
     // 4. fallback: the adaptive f32 kernel + its re-rank (verified for l2, with its exact tail) for flagged query tiles
     //    (256 * qg queries = 2 * qg of its tiles)
-    return launch_bf_adaptive_f32(f.fallback, space, dim, k, base_orig, sel_rows, aux, queries_orig, queries_sel, nullptr, bmax,
+    return launch_bf_adaptive_f32(f.fallback, space, dim, k, base_orig, sel_rows, aux, queries_orig,
+                                  f.cosc ? queries_centred : queries_sel, f.cosc ? qaux_cosc : nullptr, bmax,
                                   cand_fb, cnt_fb, flags_fb, ext_ids, out_ids, out_dists, out_cnt, tile_fail, f.tq / 128, s,
                                   /*cleared=*/true);
 }
@@ -3783,6 +3877,20 @@ hipError_t launch_query_aux_cosc(const float* orig, const float* centred, int nq
     if (nq == 0) return hipSuccess;
     hipLaunchKernelGGL(query_aux_cosc_kernel, dim3((nq + 3) / 4), dim3(256), 0, s, orig, centred, nq, ldb, dim, mu_norm,
                        qaux);
+    return hipGetLastError();
+}
+hipError_t launch_row_aug_cosc(const float* orig, const float* centred, int n, int ldb, int dim, double mu_norm, float lambda,
+                               float* out, int ldo, int* zero_rows, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(row_aug_cosc_kernel, dim3((n + 3) / 4), dim3(256), 0, s, orig, centred, n, ldb, dim, mu_norm, lambda, out,
+                       ldo, zero_rows);
+    return hipGetLastError();
+}
+hipError_t launch_query_aug_cosc(const float* centred, const float* qaux, int nq, int qpad, int ldb, int dim, float lambda,
+                                 float* out, int ldo, hipStream_t s) {
+    if (qpad == 0) return hipSuccess;
+    hipLaunchKernelGGL(query_aug_cosc_kernel, dim3((qpad + 3) / 4), dim3(256), 0, s, centred, qaux, nq, qpad, ldb, dim, lambda,
+                       out, ldo);
     return hipGetLastError();
 }
 hipError_t launch_col_stats(const float* base, int n, int ldb, int dim, double* stats, hipStream_t s) {

@@ -121,8 +121,10 @@ hipError_t launch_bf_select_f32_ex(const BfPlan& p, int space, const float* base
 // exact f32 re-rank with verification, adaptive fallback).  Exact like the adaptive path.
 struct BfF32Fast {
     bool use;
-    int mode;                  // 0 l2, 1 negdotprod, 2 cosine / angular (uncentred)
+    int mode;                  // 0 l2, 1 negdotprod (and centred cosine / angular, see cosc), 2 cosine / angular (uncentred)
     int qg;                    // a scan workgroup serves 256 * qg queries (= one query tile)
+    bool cosc;                 // centred cosine / angular: mode 1 over augmented rows of sel_dim = dim + 3 columns
+    int sel_dim;               // columns of the selection rows / queries (dim, or dim + 3)
     int kch;                   // rows longer than 128: chunks of 128 dimensions per row (1 = the classic shape)
     int dp;                    // 128 * kch: row length of the bf16 tiles
     int tq;                    // queries per scan workgroup / query tile: 256 * qg, or 128 when kch > 1
@@ -154,7 +156,13 @@ hipError_t launch_bf_f32_fast(const BfF32Fast& f, int space, int n, int dim, int
                               void* q_hi, void* q_lo, float* top8, unsigned long long* cand_fb, int* cnt_fb, float* thr,
                               uint32_t* list, int* list_cnt, int* tile_fail, int* flags_fb, const int32_t* ext_ids, int32_t* out_ids,
                               float* out_dists, int32_t* out_cnt, hipEvent_t scan_begin, hipEvent_t scan_end,
-                              hipStream_t s, const float* queries_raw = nullptr, float* queries_pad_out = nullptr);
+                              hipStream_t s, const float* queries_raw = nullptr, float* queries_pad_out = nullptr,
+                              const float* qaux_cosc = nullptr, const float* queries_centred = nullptr, int sel_ld = 0);
+// centred cosine / angular on the fast path: augmented rows / queries (see row_aug_cosc_kernel)
+hipError_t launch_row_aug_cosc(const float* orig, const float* centred, int n, int ldb, int dim, double mu_norm, float lambda,
+                               float* out, int ldo, int* zero_rows, hipStream_t s);
+hipError_t launch_query_aug_cosc(const float* centred, const float* qaux, int nq, int qpad, int ldb, int dim, float lambda,
+                                 float* out, int ldo, hipStream_t s);
 
 // The adaptive f32 path end to end (selection, re-rank; l2: verification + exact tail).  flags: [p.nqt] ints.
 hipError_t launch_bf_adaptive_f32(const BfPlan& p, int space, int dim, int k, const float* base_orig, const float* sel_rows,

@@ -706,3 +706,46 @@ def test_f32_fast_path_long_rows(space, D, monkeypatch):
         r = idx.knnQueryBatch(Q, k)
         np.testing.assert_array_equal(r[0], ids)
     idx.close()
+
+
+@pytest.mark.parametrize("space", ["cosinesimil", "angulardist"])
+@pytest.mark.parametrize("kind", ["siftlike128", "offset32", "offset200"])
+def test_centred_cosine_fast_path(space, kind, monkeypatch):
+    """Cosine / angular on rows with a large common component (non-negative features, offsets): the selection runs on
+    centred rows, and since round 3 on the bf16 fast path too -- the score -(1 - cos)|q| as an inner product of rows and
+    queries with three more columns (row_aug_cosc_kernel).  70k rows, 300 queries: path 1, the oracle's answers, and the
+    adaptive centred path's (NMSLIB_GPU_COSC_FAST=0) bit for bit."""
+    n, nq, k = 70000, 300, 10
+    if kind == "siftlike128":
+        X, Q = refio.s_sift_like(n, 401).astype(np.float32), refio.s_sift_like(nq, 402).astype(np.float32)
+    else:
+        D = 32 if kind == "offset32" else 200
+        X = (refio.s_lowrank(n, D, 403) + np.float32(1.5)).astype(np.float32)
+        Q = (refio.s_lowrank(nq, D, 404) + np.float32(1.5)).astype(np.float32)
+    idx = make_index(space, "seq_search", X)
+    ids, ds, cnt = idx.knnQueryBatch(Q, k)
+    st = idx.stats()
+    print(kind, space, st)
+    assert st["last_path"] == 1 and st["fast_tiles"] > 0, st
+    assert st["fast_tiles_fallback"] == 0, st
+    monkeypatch.setenv("NMSLIB_GPU_COSC_FAST", "0")
+    ids0, ds0, _ = idx.knnQueryBatch(Q, k)
+    assert idx.stats()["last_path"] == 0
+    monkeypatch.delenv("NMSLIB_GPU_COSC_FAST")
+    np.testing.assert_array_equal(ids, ids0)
+    np.testing.assert_array_equal(ds.view(np.uint32), ds0.view(np.uint32))
+    sel = np.r_[0:12, nq - 12:nq]
+    opos, odist, _ = orc.seq_search(space, X, Q[sel], k + 22)
+    assert refio.recall_nmslib(ids[sel], opos, odist, k) >= 0.999
+    assert close_rel(ds[sel], odist[:, :k], rtol=1e-5, atol=1e-6)
+    Q[7] = 0.0                                           # a zero-norm query: its tile goes to the adaptive kernel
+    ids1, ds1, _ = idx.knnQueryBatch(Q, k)
+    assert idx.stats()["fast_tiles_fallback"] >= 1
+    keep = np.arange(nq) != 7
+    np.testing.assert_array_equal(ids1[keep], ids[keep])
+    monkeypatch.setenv("NMSLIB_GPU_COSC_FAST", "0")
+    ids2, ds2, _ = idx.knnQueryBatch(Q, k)
+    monkeypatch.delenv("NMSLIB_GPU_COSC_FAST")
+    np.testing.assert_array_equal(ids1, ids2)
+    np.testing.assert_array_equal(ds1.view(np.uint32), ds2.view(np.uint32))
+    idx.close()
