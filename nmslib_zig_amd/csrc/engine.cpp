@@ -1092,7 +1092,7 @@ void Engine::knn_brute(const void* d_queries, size_t nq, size_t k, int32_t* d_id
             ws_u8_listcnt_.ensure(bf_u8_listcnt_elems(f) * 4);
             int* thr = ws_u8_thr_.as<int>();
             int* tile_fail = thr + f.qpad;
-            hip_check(launch_pad_rows(d_queries, (int)nq, 128, ws_qpad_.ptr(), f.qpad, 128, 1, stream), "pad queries");
+            // (padding happens inside the fast path's one preparation kernel)
             hipEvent_t eb = nullptr, ee = nullptr;
             if (prof_ && prof_events_.size() < 65536) {
                 hip_check(hipEventCreate(&eb), "hipEventCreate");
@@ -1104,7 +1104,8 @@ void Engine::knn_brute(const void* d_queries, size_t nq, size_t k, int32_t* d_id
                                         ws_u8_cand_.as<int>(),
                                         ws_cand_.as<unsigned long long>(), ws_cnt_.as<int>(), thr,
                                         ws_u8_list_.as<uint32_t>(), ws_u8_listcnt_.as<int>(), tile_fail,
-                                        d_ids_.as<int32_t>(), d_ids, d_dists, d_cnt, eb, ee, stream),
+                                        d_ids_.as<int32_t>(), d_ids, d_dists, d_cnt, eb, ee, stream,
+                                        static_cast<const uint8_t*>(d_queries)),
                       "bf_u8_fast");
             last_path = 3;
             fast_flags_ = tile_fail;
@@ -1234,8 +1235,9 @@ void Engine::knn_hnsw(const void* d_queries, size_t nq, size_t k, int32_t* d_ids
         knn_hnsw_old(d_queries, nq, k, d_ids, d_dists, d_cnt, stream);
         return;
     }
-    if (std::max<size_t>(ef, k) > 1024) {
-        // beyond the LDS kernels' sorted array: the same algorithm with the array in HBM (slices of bounded workspace)
+    if (std::max<size_t>(ef, k) > 1024 || dg_.maxM0 > 126 || dg_.maxM > 62) {
+        // beyond the LDS kernels' sorted array, or adjacency lists longer than two words per lane (M / maxM > 62,
+        // maxM0 > 126): the same algorithm with the array in HBM and lists walked in chunks (slices of bounded workspace)
         int32_t* cnt2 = d_cnt;
         if (!cnt2) {
             ws_outcnt_.ensure(nq * 4);
@@ -1652,7 +1654,7 @@ std::unique_ptr<Engine> Engine::load(const std::string& path, int data_type, int
             default: throw EngineError(Err::DataIO, "Unknown distance function code in index file");
         }
         if (data_type != 0) throw EngineError(Err::DataIO, "an optimized HNSW index holds dense float vectors");
-        if (off_l0 < off_data + 16 || mem_per_obj < off_l0 + (maxM0 + 1) * 4 || maxM0 > 126 || maxM > 62)
+        if (off_l0 < off_data + 16 || mem_per_obj < off_l0 + (maxM0 + 1) * 4 || maxM0 > 8192 || maxM > 4096)
             throw EngineError(Err::DataIO, "unsupported optimized index geometry");
         e.reset(new Engine(space, "hnsw", data_type, dist_type));
         const size_t dim = (off_l0 - off_data - 16) / 4;

@@ -257,7 +257,8 @@ class Builder {
         cand.push({d, ep});
         rs.push({d, ep});
         vis[ep] = epoch;
-        int32_t nb[128];
+        std::vector<int32_t> nbv((size_t)std::max(maxM0_, maxM_) + 1);   // (any M: hnsw.cc:189-208)
+        int32_t* nb = nbv.data();
         while (!cand.empty()) {
             const Farther cur = cand.top();
             if (cur.d > rs.top().d) break;
@@ -295,7 +296,8 @@ class Builder {
         if (curlevel < maxlevelcopy) {
             float curdist = dist_(id, ep);
             int cur = ep;
-            int32_t nb[128];
+            std::vector<int32_t> nbv((size_t)std::max(maxM0_, maxM_) + 1);
+            int32_t* nb = nbv.data();
             for (int level = maxlevelcopy; level > curlevel; --level) {
                 bool changed = true;
                 while (changed) {
@@ -406,11 +408,11 @@ class Builder {
 }  // namespace
 
 void hnsw_check_params(const HnswBuildParams& bp) {
-    // one wavefront walks a node: upper-level lists (maxM) and the selection (M) fit one word per lane,
-    // level-0 lists (maxM0) two words per lane
-    if (bp.M < 1 || bp.M > 62 || bp.maxM < 1 || bp.maxM > 62 || bp.maxM0 < 1 || bp.maxM0 > 126)
-        throw EngineError(Err::IndexBuildFailed,
-                          "HNSW: M and maxM must be in [1, 62] and maxM0 in [1, 126] on the GPU engine");
+    // any M, as the reference (hnsw.cc:189-208).  Up to M / maxM 62 and maxM0 126 one wavefront holds a list in one or two
+    // words per lane (the fast search kernels, the GPU builder); longer lists are built on the host and searched by the
+    // kernels that walk lists in chunks (hnsw_kernels.hip, collect_unvisited_any).  The bound below only keeps sizes sane.
+    if (bp.M < 1 || bp.M > 4096 || bp.maxM < 1 || bp.maxM > 4096 || bp.maxM0 < 1 || bp.maxM0 > 8192)
+        throw EngineError(Err::IndexBuildFailed, "HNSW: M / maxM must be in [1, 4096] and maxM0 in [1, 8192]");
     if (bp.delaunay != 0 && bp.delaunay != 2)
         throw EngineError(Err::IndexBuildFailed, "HNSW: delaunay_type must be 0 or 2 on the GPU engine");
     if (bp.post != 0) throw EngineError(Err::IndexBuildFailed, "HNSW: post-processing (post=1,2) is not supported");

@@ -2793,6 +2793,24 @@ __global__ void pad_rows_kernel(const uint8_t* src, int rows, int row_bytes, uin
     }
 }
 
+// Query preparation of the uint8 fast path in ONE launch (round 3; was pad_rows + two fillBuffers): the padded queries and
+// the words later kernels of the batch expect cleared (tile flags, the fallback selection's shared thresholds)
+__global__ void bf_u8_prep_kernel(const uint8_t* raw, int nq, uint8_t* padded, int qpad, int* clr0, int n0, uint32_t* clr1,
+                                  size_t n1) {
+    const size_t gtid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, gsz = (size_t)gridDim.x * blockDim.x;
+    if ((reinterpret_cast<uintptr_t>(raw) & 3) == 0) {   // 128-byte rows as 32-bit words
+        const size_t words = (size_t)qpad * 32;
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(raw);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(padded);
+        for (size_t i = gtid; i < words; i += gsz) dst[i] = i < (size_t)nq * 32 ? src[i] : 0u;
+    } else {                                             // (a caller's buffer at an odd address)
+        const size_t bytes = (size_t)qpad * 128;
+        for (size_t i = gtid; i < bytes; i += gsz) padded[i] = i < (size_t)nq * 128 ? raw[i] : (uint8_t)0;
+    }
+    for (size_t i = gtid; i < (size_t)n0; i += gsz) clr0[i] = 0;
+    for (size_t i = gtid; i < n1; i += gsz) clr1[i] = 0u;
+}
+
 // hnsw.h:486-497 NormalizeVect: v *= 1/sqrt(sum v^2) unless the sum is exactly 0
 __global__ void normalize_rows_kernel(float* rows, int n, int ld, int dim) {
     const int lane = threadIdx.x & 63;
@@ -3254,12 +3272,12 @@ hipError_t launch_bf_select_direct_f32_ex(const BfPlan& p, int space, const floa
 hipError_t launch_bf_select_u8(const BfPlan& p, const uint8_t* base_i8, const int32_t* aux,
                                const uint8_t* queries_padded, unsigned long long* cand, int* cand_cnt,
                                hipStream_t s) {
-    return launch_bf_select_u8_ex(p, base_i8, aux, queries_padded, cand, cand_cnt, 1, nullptr, 1, s);
+    return launch_bf_select_u8_ex(p, base_i8, aux, queries_padded, cand, cand_cnt, 1, nullptr, 1, s, false);
 }
 
 hipError_t launch_bf_select_u8_ex(const BfPlan& p, const uint8_t* base_i8, const int32_t* aux,
                                   const uint8_t* queries_padded, unsigned long long* cand, int* cand_cnt,
-                                  int tile_stride, const int* tile_fail, int fail_group, hipStream_t s) {
+                                  int tile_stride, const int* tile_fail, int fail_group, hipStream_t s, bool cleared) {
     BfArgsU8 a{};
     a.tile_stride = tile_stride;
     a.tile_fail = tile_fail;
@@ -3281,8 +3299,10 @@ hipError_t launch_bf_select_u8_ex(const BfPlan& p, const uint8_t* base_i8, const
     a.xm = p.xm;
     static const int dbg = getenv("NMSLIB_GPU_DEBUG") ? atoi(getenv("NMSLIB_GPU_DEBUG")) : 0;
     a.dbg = dbg;
-    hipError_t me = hipMemsetAsync(gthr, 0, ((size_t)p.qpad + (size_t)p.qpad * p.nsplit) * 4, s);
-    if (me != hipSuccess) return me;
+    if (!cleared) {   // (cleared: the caller's preparation kernel zeroed the shared thresholds at the start of the batch)
+        hipError_t me = hipMemsetAsync(gthr, 0, ((size_t)p.qpad + (size_t)p.qpad * p.nsplit) * 4, s);
+        if (me != hipSuccess) return me;
+    }
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bf_select_u8_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_select);
     if (e != hipSuccess) return e;
@@ -3428,8 +3448,20 @@ hipError_t launch_bf_u8_fast(const BfU8Fast& f, int n, int nq, int k, const uint
                              int* top8, unsigned long long* cand_fb, int* cnt_fb,
                              int* thr, uint32_t* list, int* list_cnt, int* tile_fail, const int32_t* ext_ids,
                              int32_t* out_ids, float* out_dists, int32_t* out_cnt, hipEvent_t scan_begin,
-                             hipEvent_t scan_end, hipStream_t s) {
+                             hipEvent_t scan_end, hipStream_t s, const uint8_t* queries_raw) {
     hipError_t e;
+    {   // pad the queries (queries_raw [nq][128] -> queries_padded [qpad][128]) + every clear of the batch
+        const BfPlan& fb = f.fallback;
+        uint32_t* gthr = reinterpret_cast<uint32_t*>(cnt_fb + (size_t)fb.qpad * fb.nsplit);
+        const size_t gwords = (size_t)fb.qpad + (size_t)fb.qpad * fb.nsplit;
+        const size_t work = (size_t)f.qpad * 32 > gwords ? (size_t)f.qpad * 32 : gwords;
+        size_t grid = (work + 255) / 256;
+        if (grid > 2048) grid = 2048;
+        hipLaunchKernelGGL(bf_u8_prep_kernel, dim3((unsigned)grid), dim3(256), 0, s, queries_raw, nq,
+                           const_cast<uint8_t*>(queries_padded), f.qpad, tile_fail, f.nqt, gthr, gwords);
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
     auto scan = [&](const BfScanArgs& sa, int grid) -> hipError_t {
         const void* fn = f.qg == 4 ? (const void*)bf_scan_u8_kernel<4, false> : (const void*)bf_scan_u8_kernel<2, false>;
         hipError_t le = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)f.lds_scan);
@@ -3466,9 +3498,7 @@ hipError_t launch_bf_u8_fast(const BfU8Fast& f, int n, int nq, int k, const uint
         hipLaunchKernelGGL(bf_u8_threshold_kernel<16>, dim3((f.qpad + 3) / 4), dim3(256), 0, s, top8, 2 * f.s_nsplit, f.r, nq, f.qpad, thr);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
-    e = hipMemsetAsync(tile_fail, 0, (size_t)f.nqt * 4, s);
-    if (e != hipSuccess) return e;
-    // 2. scan with fixed thresholds
+    // 2. scan with fixed thresholds (tile flags: cleared by the preparation kernel)
     BfScanArgs a{};
     a.base_i8 = base_i8;
     a.auxh = auxh;
@@ -3511,7 +3541,7 @@ hipError_t launch_bf_u8_fast(const BfU8Fast& f, int n, int nq, int k, const uint
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     // 4. fallback for flagged tile groups (workgroups of clear groups leave at once)
-    e = launch_bf_select_u8_ex(f.fallback, base_i8, aux, queries_padded, cand_fb, cnt_fb, 1, tile_fail, f.qg, s);
+    e = launch_bf_select_u8_ex(f.fallback, base_i8, aux, queries_padded, cand_fb, cnt_fb, 1, tile_fail, f.qg, s, /*cleared=*/true);
     if (e != hipSuccess) return e;
     return launch_bf_rerank_ex(f.fallback, SP_L2SQR_SIFT, 128, k, base_u8, queries_padded, cand_fb, cnt_fb, ext_ids, out_ids,
                                out_dists, out_cnt, tile_fail, BF_TQ * f.qg, s);

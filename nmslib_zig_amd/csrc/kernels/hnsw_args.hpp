@@ -5,6 +5,12 @@
 
 namespace gfxknn {
 
+// entries of the frontier arrays: a multiple of 64 that holds the longest adjacency list (level 0 or above)
+inline int hnsw_nbcap(const HnswDeviceGraph& g) {
+    const int longest = g.maxM0 > g.maxM ? g.maxM0 : g.maxM;
+    return longest <= 62 ? 64 : (longest + 64) / 64 * 64;
+}
+
 struct HnswArgs {
     HnswDeviceGraph g;
     const void* queries;
@@ -18,6 +24,7 @@ struct HnswArgs {
     int32_t* out_hops_up;
     int32_t* status;
     int nq, k, ef, cap;
+    int nbcap;  // SearchOld / HBM-array SearchV1Merge with wide lists: entries of the frontier arrays (hnsw_nbcap)
     int capa;  // cap rounded up to a multiple of 4 (keeps the LDS carve-up 16-byte aligned)
     // construction mode (hnsw_build_kernels.hip): the query is a stored row, the best-first phase runs
     // on `level`, and the start node is given (or found by descending from the entry point to level+1)

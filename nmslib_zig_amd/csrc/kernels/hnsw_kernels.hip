@@ -615,13 +615,68 @@ __device__ __forceinline__ u64 pack_kid(float key, int id) { return ((u64)__floa
 __device__ __forceinline__ float kid_key(u64 v) { return __uint_as_float((uint32_t)(v >> 32)); }
 __device__ __forceinline__ int kid_id(u64 v) { return (int)(uint32_t)v; }
 
+// ---- adjacency lists of any length (round 3: M / maxM > 62, maxM0 > 126 -- hnsw.cc:189-208 takes any M) -------------
+// The kernels above give a list one or two words per lane.  SearchOld and the HBM-array SearchV1Merge walk longer lists in
+// chunks of 64 neighbours (list order kept: neighbour i is list word i + 1); their frontier arrays hold a.nbcap entries.
+// unvisited neighbours of list[] -> nbr[0 .. m), returns m
+template <class Visit>
+__device__ __forceinline__ int collect_unvisited_any(const int* list, int* nbr, int lane, Visit&& visit) {
+    const int cnt = __builtin_amdgcn_readfirstlane(list[0]);
+    int m = 0;
+    for (int c0 = 0; c0 < cnt; c0 += 64) {
+        const int i = c0 + lane;
+        const int nb = i < cnt ? list[i + 1] : 0;
+        bool isn = false;
+        if (i < cnt) isn = visit((uint32_t)nb);
+        const u64 mask = __ballot(isn);
+        if (isn) nbr[m + __popcll(mask & ((1ull << lane) - 1ull))] = nb;
+        m += __popcll(mask);
+    }
+    return m;
+}
+// one greedy step on an upper level over a list of any length: the FIRST neighbour attaining the minimum, if it is closer
+// than curdist (the sequential "if (d < curdist)" scan of hnsw.cc / hnsw_distfunc_opt.cc:176-196).  Returns the list length.
+template <int SPACE>
+__device__ __forceinline__ int greedy_step_any(const HnswDeviceGraph& g, const int* list, const float* qv, const uint8_t* qb,
+                                               int qnorm, int* nbr, float* nd, int lane, int& cur, float& curdist,
+                                               bool& changed) {
+    const int cnt = __builtin_amdgcn_readfirstlane(list[0]);
+    for (int c0 = 0; c0 < cnt; c0 += 64)
+        if (c0 + lane < cnt) nbr[c0 + lane] = list[c0 + lane + 1];
+    __builtin_amdgcn_wave_barrier();
+    if (cnt > 0) {
+        frontier_distances<SPACE>(g, qv, qb, qnorm, nbr, nd, cnt, lane);
+        u64 key = ~0ull;
+        for (int c0 = 0; c0 < cnt; c0 += 64) {
+            const int i = c0 + lane;
+            if (i < cnt) {
+                const u64 k2 = ((u64)f32_ord(nd[i]) << 32) | (uint32_t)i;
+                key = k2 < key ? k2 : key;
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const u64 other = __shfl_xor(key, o, 64);
+            key = other < key ? other : key;
+        }
+        const float dmin = ord_f32((uint32_t)(key >> 32));
+        if (dmin < curdist) {
+            curdist = dmin;
+            cur = nbr[(uint32_t)key];
+            changed = true;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    return cnt;
+}
+
 template <int SPACE, bool BITSET, bool WIDE>
 __global__ __launch_bounds__(64) void hnsw_search_old_kernel(HnswArgs a, OldWs w) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const HnswDeviceGraph& g = a.g;
     const int q = blockIdx.x, lane = threadIdx.x;
     constexpr bool kU8 = DistTraits<SPACE>::kU8;
-    constexpr int nbcap = WIDE ? 128 : 64;
+    const int nbcap = WIDE ? a.nbcap : 64;   // (wide lists: a multiple of 64 that holds maxM0 and maxM)
 
     // ---- LDS carve-up ----
     const int qfloats = kU8 ? 32 : g.ldv;
@@ -719,6 +774,11 @@ __global__ __launch_bounds__(64) void hnsw_search_old_kernel(HnswArgs a, OldWs w
         while (changed) {
             changed = false;
             const int64_t off = g.up_off[cur] + (int64_t)(lvl - 1) * (g.maxM + 1);
+            if (WIDE && g.maxM > 62) {   // upper-level lists of any length
+                hops_up++;
+                ndc += greedy_step_any<SPACE>(g, g.up_links + off, qv, qb, qnorm, nbr, nd, lane, cur, curdist, changed);
+                continue;
+            }
             const int v = (lane <= g.maxM) ? g.up_links[off + lane] : 0;
             const int cntl = __builtin_amdgcn_readfirstlane(v);
             const int nb = __shfl(v, lane + 1, 64);
@@ -817,22 +877,18 @@ __global__ __launch_bounds__(64) void hnsw_search_old_kernel(HnswArgs a, OldWs w
         const int c = kid_id(top);
         hops++;
         // adjacency [count][ids...]
-        const int v = (lane <= g.maxM0) ? g.links0[(size_t)c * (g.maxM0 + 1) + lane] : 0;
-        const int cntn = __builtin_amdgcn_readfirstlane(v);
-        const int nb = __shfl(v, lane + 1, 64);
-        bool isn = false;
-        if (lane < cntn && (!WIDE || lane < 63)) isn = visit((uint32_t)nb);
-        const u64 nmask = __ballot(isn);
-        int m = __popcll(nmask);
-        if (isn) nbr[__popcll(nmask & ((1ull << lane) - 1ull))] = nb;
-        if (WIDE && cntn > 63) {
-            int nb2 = 0;
-            if (64 + lane <= g.maxM0) nb2 = g.links0[(size_t)c * (g.maxM0 + 1) + 64 + lane];
-            bool isn2 = false;
-            if (63 + lane < cntn) isn2 = visit((uint32_t)nb2);
-            const u64 nmask2 = __ballot(isn2);
-            if (isn2) nbr[m + __popcll(nmask2 & ((1ull << lane) - 1ull))] = nb2;
-            m += __popcll(nmask2);
+        int m;
+        if constexpr (WIDE) {   // lists of any length, chunks of 64 neighbours
+            m = collect_unvisited_any(g.links0 + (size_t)c * (g.maxM0 + 1), nbr, lane, visit);
+        } else {
+            const int v = (lane <= g.maxM0) ? g.links0[(size_t)c * (g.maxM0 + 1) + lane] : 0;
+            const int cntn = __builtin_amdgcn_readfirstlane(v);
+            const int nb = __shfl(v, lane + 1, 64);
+            bool isn = false;
+            if (lane < cntn) isn = visit((uint32_t)nb);
+            const u64 nmask = __ballot(isn);
+            m = __popcll(nmask);
+            if (isn) nbr[__popcll(nmask & ((1ull << lane) - 1ull))] = nb;
         }
         nvisited += m;
         if (!BITSET && nvisited > (a.table_size - (a.table_size >> 3))) {
@@ -992,7 +1048,7 @@ __global__ __launch_bounds__(64) void hnsw_search_big_kernel(HnswArgs a, float* 
     const HnswDeviceGraph& g = a.g;
     const int q = blockIdx.x, lane = threadIdx.x;
     constexpr bool kU8 = DistTraits<SPACE>::kU8;
-    constexpr int nbcap = WIDE ? 128 : 64;
+    const int nbcap = WIDE ? a.nbcap : 64;   // (wide lists: a multiple of 64 that holds maxM0 and maxM)
     const int qfloats = kU8 ? 32 : g.ldv;
     float* qv = reinterpret_cast<float*>(smem);
     int* nbr = reinterpret_cast<int*>(qv + qfloats);
@@ -1059,6 +1115,11 @@ __global__ __launch_bounds__(64) void hnsw_search_big_kernel(HnswArgs a, float* 
         while (changed) {
             changed = false;
             const int64_t off = g.up_off[cur] + (int64_t)(lvl - 1) * (g.maxM + 1);
+            if (WIDE && g.maxM > 62) {   // upper-level lists of any length
+                hops_up++;
+                ndc += greedy_step_any<SPACE>(g, g.up_links + off, qv, qb, qnorm, nbr, nd, lane, cur, curdist, changed);
+                continue;
+            }
             const int v = (lane <= g.maxM) ? g.up_links[off + lane] : 0;
             const int cntl = __builtin_amdgcn_readfirstlane(v);
             const int nb = __shfl(v, lane + 1, 64);
@@ -1111,22 +1172,18 @@ __global__ __launch_bounds__(64) void hnsw_search_big_kernel(HnswArgs a, float* 
         const int size0 = n;
         wave_sync();
         // adjacency [count][ids...] -> unvisited neighbours
-        const int v = (lane <= g.maxM0) ? g.links0[(size_t)c * (g.maxM0 + 1) + lane] : 0;
-        const int cntn = __builtin_amdgcn_readfirstlane(v);
-        const int nb = __shfl(v, lane + 1, 64);
-        bool isn = false;
-        if (lane < cntn && (!WIDE || lane < 63)) isn = visit((uint32_t)nb);
-        const u64 nmask = __ballot(isn);
-        int m = __popcll(nmask);
-        if (isn) nbr[__popcll(nmask & ((1ull << lane) - 1ull))] = nb;
-        if (WIDE && cntn > 63) {
-            int nb2 = 0;
-            if (64 + lane <= g.maxM0) nb2 = g.links0[(size_t)c * (g.maxM0 + 1) + 64 + lane];
-            bool isn2 = false;
-            if (63 + lane < cntn) isn2 = visit((uint32_t)nb2);
-            const u64 nmask2 = __ballot(isn2);
-            if (isn2) nbr[m + __popcll(nmask2 & ((1ull << lane) - 1ull))] = nb2;
-            m += __popcll(nmask2);
+        int m;
+        if constexpr (WIDE) {   // lists of any length, chunks of 64 neighbours
+            m = collect_unvisited_any(g.links0 + (size_t)c * (g.maxM0 + 1), nbr, lane, visit);
+        } else {
+            const int v = (lane <= g.maxM0) ? g.links0[(size_t)c * (g.maxM0 + 1) + lane] : 0;
+            const int cntn = __builtin_amdgcn_readfirstlane(v);
+            const int nb = __shfl(v, lane + 1, 64);
+            bool isn = false;
+            if (lane < cntn) isn = visit((uint32_t)nb);
+            const u64 nmask = __ballot(isn);
+            m = __popcll(nmask);
+            if (isn) nbr[__popcll(nmask & ((1ull << lane) - 1ull))] = nb;
         }
         __builtin_amdgcn_wave_barrier();
         if (m == 0) continue;
@@ -1444,7 +1501,7 @@ HnswSearchPlan hnsw_make_plan_old(const HnswDeviceGraph& g, int nq, int k, int e
     if (hc > (long long)g.n + 1) hc = (long long)g.n + 1;
     p.heap_cap = (int)hc;
     p.heap_lds = p.heap_cap < 2048 ? p.heap_cap : 2048;
-    const int nbcap = g.maxM0 > 62 ? 128 : 64;
+    const int nbcap = hnsw_nbcap(g);
     const size_t fixed = (u8 ? 128 : (size_t)g.ldv * 4) + (size_t)(2 * nbcap + 64) * 4 + (size_t)p.heap_lds * 8 +
                          (p.a_in_lds ? (size_t)((ef + 1) & ~1) * 4 : 0) + (p.r_in_lds ? (size_t)k * 8 : 0);
     int want = 1 << ilog2((g.maxM0 > 0 ? g.maxM0 : 32) * p.cap * 2);
@@ -1472,7 +1529,7 @@ static hipError_t launch_old_space(const HnswArgs& a, const OldWs& w, const Hnsw
         hipLaunchKernelGGL(kern, dim3(a.nq), dim3(64), p.lds_bytes, s, a, w);
         return hipGetLastError();
     };
-    const bool wide = a.g.maxM0 > 62;
+    const bool wide = a.g.maxM0 > 62 || a.g.maxM > 62;
     if (p.table_size == 0) return wide ? go(hnsw_search_old_kernel<SPACE, true, true>) : go(hnsw_search_old_kernel<SPACE, true, false>);
     return wide ? go(hnsw_search_old_kernel<SPACE, false, true>) : go(hnsw_search_old_kernel<SPACE, false, false>);
 }
@@ -1482,9 +1539,9 @@ hipError_t launch_hnsw_search_old(const HnswDeviceGraph& g, const HnswSearchPlan
                                   float* out_dists, int32_t* out_cnt, int32_t* out_ndc, int32_t* out_hops,
                                   int32_t* out_hops_up, int32_t* status, hipStream_t s) {
     if (p.nq == 0) return hipSuccess;
-    if (g.maxM0 > 126 || g.maxM > 62) return hipErrorInvalidValue;
     HnswArgs a{};
     a.g = g;
+    a.nbcap = hnsw_nbcap(g);
     a.queries = queries;
     a.level = 0;
     a.bitset = bitset;
@@ -1530,7 +1587,7 @@ hipError_t launch_hnsw_search_old(const HnswDeviceGraph& g, const HnswSearchPlan
 // ---- SearchV1Merge beyond 1024 items (hnsw_search_big_kernel) ---------------------------------------------------
 template <int SPACE>
 static hipError_t launch_big_space(const HnswArgs& a, float* ws_keys, int32_t* ws_idu, size_t lds, hipStream_t s) {
-    if (a.g.maxM0 > 62) hipLaunchKernelGGL((hnsw_search_big_kernel<SPACE, true>), dim3(a.nq), dim3(64), lds, s, a, ws_keys, ws_idu);
+    if (a.g.maxM0 > 62 || a.g.maxM > 62) hipLaunchKernelGGL((hnsw_search_big_kernel<SPACE, true>), dim3(a.nq), dim3(64), lds, s, a, ws_keys, ws_idu);
     else hipLaunchKernelGGL((hnsw_search_big_kernel<SPACE, false>), dim3(a.nq), dim3(64), lds, s, a, ws_keys, ws_idu);
     return hipGetLastError();
 }
@@ -1539,9 +1596,9 @@ hipError_t launch_hnsw_search_big(const HnswDeviceGraph& g, int nq, int k, int e
                                   float* ws_keys, int32_t* ws_idu, int32_t* out_ids, float* out_dists, int32_t* out_cnt,
                                   int32_t* out_ndc, int32_t* out_hops, int32_t* out_hops_up, int32_t* status, hipStream_t s) {
     if (nq == 0) return hipSuccess;
-    if (g.maxM0 > 126 || g.maxM > 62) return hipErrorInvalidValue;
     HnswArgs a{};
     a.g = g;
+    a.nbcap = hnsw_nbcap(g);
     a.queries = queries;
     a.bitset = bitset;
     a.bitset_words = ((size_t)g.n + 31) / 32;
@@ -1557,7 +1614,7 @@ hipError_t launch_hnsw_search_big(const HnswDeviceGraph& g, int nq, int k, int e
     a.ef = ef;
     a.cap = ef > k ? ef : k;
     const bool u8 = g.space == SP_L2SQR_SIFT;
-    const size_t lds = (u8 ? 128 : (size_t)g.ldv * 4) + (size_t)(2 * (g.maxM0 > 62 ? 128 : 64) + 2 * 64) * 4 + 16;
+    const size_t lds = (u8 ? 128 : (size_t)g.ldv * 4) + (size_t)(2 * hnsw_nbcap(g) + 2 * 64) * 4 + 16;
     switch (g.space) {
         case SP_L2SQR: return launch_big_space<SP_L2SQR>(a, ws_keys, ws_idu, lds, s);
         case SP_L2: return launch_big_space<SP_L2>(a, ws_keys, ws_idu, lds, s);

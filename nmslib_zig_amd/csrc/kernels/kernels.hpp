@@ -87,7 +87,7 @@ hipError_t launch_bf_select_u8(const BfPlan& p, const uint8_t* base_i8, const in
 // ... over every tile_stride-th 64-row tile only, and/or only for the query-tile groups flagged in tile_fail
 hipError_t launch_bf_select_u8_ex(const BfPlan& p, const uint8_t* base_i8, const int32_t* aux,
                                   const uint8_t* queries_padded, unsigned long long* cand, int* cand_cnt,
-                                  int tile_stride, const int* tile_fail, int fail_group, hipStream_t s);
+                                  int tile_stride, const int* tile_fail, int fail_group, hipStream_t s, bool cleared = false);
 
 // uint8 fast path for large batches (bf_kernels.hip: sample pass -> fixed-threshold scan -> list re-rank with
 // verification -> adaptive fallback for flagged tile groups).  Exact like the adaptive path.
@@ -111,7 +111,7 @@ hipError_t launch_bf_u8_fast(const BfU8Fast& f, int n, int nq, int k, const uint
                              int* top8, unsigned long long* cand_fb, int* cnt_fb,
                              int* thr, uint32_t* list, int* list_cnt, int* tile_fail, const int32_t* ext_ids,
                              int32_t* out_ids, float* out_dists, int32_t* out_cnt, hipEvent_t scan_begin,
-                             hipEvent_t scan_end, hipStream_t s);
+                             hipEvent_t scan_end, hipStream_t s, const uint8_t* queries_raw);
 
 hipError_t launch_bf_select_f32_ex(const BfPlan& p, int space, const float* base, const float* aux,
                                    const float* queries_padded, const float* qaux_cosc, unsigned long long* cand,

@@ -46,3 +46,33 @@ def test_v1merge_big_with_ties_is_exact():
     np.testing.assert_array_equal(ndc, ondc)
     np.testing.assert_array_equal(hops, ohops)
     idx.close()
+
+
+@pytest.mark.parametrize("space,M,maxM,maxM0", [("l2", 64, None, None), ("cosinesimil", 70, None, None), ("l2", 20, 90, 200)])
+def test_any_M_same_graph_same_walk(space, M, maxM, maxM0, tmp_path):
+    """M / maxM > 62 or maxM0 > 126 (hnsw.cc:189-208 takes any M): built on the host in the reference's order, searched by
+    the kernels that walk adjacency lists in chunks of 64 (collect_unvisited_any).  Same graph as the oracle's build, and on
+    it the same ids, distances and work counters for SearchV1Merge and SearchOld."""
+    from tests.test_gpu_hnsw_build import graph_of
+    n, D, nq, k = 4000, 24, 96, 10
+    X, Q = refio.s_lowrank(n, D, 811), refio.s_lowrank(nq, D, 812)
+    extra = {}
+    if maxM is not None:
+        extra = dict(maxM=maxM, maxM0=maxM0)
+    idx = make_index(space, "hnsw", X, M=M, efConstruction=120, indexThreadQty=1, **extra)
+    g = orc.HnswGraph.build(space, X, M, 120, maxM=maxM, maxM0=maxM0)
+    got = graph_of(idx, tmp_path, "wide.idx")
+    np.testing.assert_array_equal(got["links0"], g.links0())
+    assert got["links0"][:, 0].max() > 63                     # (lists really are longer than one word per lane)
+    for algo in ("v1merge", "old"):
+        for ef in (40, 150):
+            idx.setQueryTimeParams(efSearch=ef, algoType=algo)
+            ids, ds, cnt = idx.knnQueryBatch(Q, k)
+            opos, odist, ocnt, ondc, ohops = g.search(Q, k, ef, algo=algo)
+            np.testing.assert_array_equal(ids, opos)
+            assert close_rel(ds, odist)
+            ndc, hops, hops_up = (x.astype(np.int64) for x in idx.read_counters(nq))
+            if algo == "v1merge":
+                np.testing.assert_array_equal(ndc, ondc)
+                np.testing.assert_array_equal(hops, ohops)
+    idx.close()
