@@ -459,6 +459,9 @@ void Engine::upload_graph() {
 
 bool Engine::use_gpu_build() const {
     if (loaded_graph_ || method_ != Method::Hnsw) return false;
+    // what only the host builder does (the reference's "no limits"): lists beyond two words per lane, selection
+    // heuristics 1 and 3, post-processing -- also when gpu_build=1 asks for the GPU
+    if (bp_.maxM > 62 || bp_.maxM0 > 126 || bp_.M > 62 || bp_.delaunay == 1 || bp_.delaunay == 3 || bp_.post != 0) return false;
     if (bp_.gpu_build >= 0) return bp_.gpu_build != 0;
     // auto: indexThreadQty=1 asks for the reference's sequential insertion order (bit-identical graph,
     // host builder); anything else is the concurrent build, whose schedule is free -> the GPU, unless the

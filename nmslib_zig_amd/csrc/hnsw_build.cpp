@@ -18,6 +18,7 @@
 #include <queue>
 #include <random>
 #include <thread>
+#include <unordered_set>
 
 #include "engine.hpp"
 
@@ -210,6 +211,99 @@ class Builder {
         for (const Farther& r : ret) rs.push({r.d, r.id});
     }
 
+    // getNeighborsByHeuristic1, hnsw.h:82-127: heuristic 2 that tops the list up with the closest rejected items
+    void heuristic1(std::priority_queue<Closer>& rs, size_t NN) {
+        if (rs.size() < NN) return;
+        std::priority_queue<Farther> closest, rejected;
+        std::vector<Farther> ret;
+        while (!rs.empty()) {
+            closest.push({rs.top().d, rs.top().id});
+            rs.pop();
+        }
+        while (!closest.empty()) {
+            if (ret.size() >= NN) break;
+            const Farther cur = closest.top();
+            closest.pop();
+            bool good = true;
+            for (const Farther& r : ret) {
+                if (dist_(r.id, cur.id) < cur.d) {
+                    good = false;
+                    break;
+                }
+            }
+            if (good) ret.push_back(cur);
+            else rejected.push(cur);
+        }
+        while (ret.size() < NN && !rejected.empty()) {
+            ret.push_back(rejected.top());
+            rejected.pop();
+        }
+        for (const Farther& r : ret) rs.push({r.d, r.id});
+    }
+
+    // getNeighborsByHeuristic3, hnsw.h:171-256: the candidates and THEIR friends on the level are ranked again; items no
+    // kept item is closer to go first ("high priority"), then those only a rejected item is closer to.  The reference gathers
+    // the candidates in an unordered_set of node addresses: its iteration order (the allocator's) decides only the order
+    // among equal distances; here they enter in order of first appearance.
+    void heuristic3(std::priority_queue<Closer>& rs, size_t NN, int self, int level) {
+        std::vector<int> cand;
+        std::unordered_set<int> seen;
+        while (!rs.empty()) {
+            const int c = rs.top().id;
+            rs.pop();
+            if (seen.insert(c).second) cand.push_back(c);
+            const int32_t* L = links(c, level);
+            for (int i = 0; i < L[0]; ++i)
+                if (seen.insert(L[1 + i]).second) cand.push_back(L[1 + i]);
+        }
+        for (int c : cand)
+            if (c != self) rs.push({dist_(c, self), c});
+        if (rs.size() < NN) return;
+        std::vector<Closer> input(rs.size()), rejected, second, first;
+        for (int i = (int)rs.size() - 1; i >= 0; --i) {
+            input[(size_t)i] = rs.top();
+            rs.pop();
+        }
+        for (const Closer& cur : input) {
+            if (first.size() >= NN) break;
+            int good = 2;
+            for (const Closer& r : rejected)
+                if (dist_(r.id, cur.id) < cur.d) {
+                    good = 1;
+                    break;
+                }
+            for (const Closer& r : first)
+                if (dist_(r.id, cur.id) < cur.d) {
+                    good = 0;
+                    break;
+                }
+            if (good)
+                for (const Closer& r : second)
+                    if (dist_(r.id, cur.id) < cur.d) {
+                        good = 0;
+                        break;
+                    }
+            if (good == 2) first.push_back(cur);
+            else if (good == 1) second.push_back(cur);
+            else rejected.push_back(cur);
+        }
+        for (const Closer& r : first) {
+            if (rs.size() >= NN) break;
+            rs.push(r);
+        }
+        for (const Closer& r : second) {
+            if (rs.size() >= NN) break;
+            rs.push(r);
+        }
+    }
+
+    // the selection of Hnsw::add (hnsw.cc:582-597) and of addFriendlevel's shrink (hnsw.h:283-289) by delaunay_type
+    void select(std::priority_queue<Closer>& rs, size_t NN, int self, int level) {
+        if (delaunay_ == 1) heuristic1(rs, NN);
+        else if (delaunay_ == 3) heuristic3(rs, NN, self, level);
+        else heuristic2(rs, NN);
+    }
+
     // addFriendlevel, hnsw.h:258-314
     void add_friend(int node, int level, int elem) {
         Guard g(locks_[node]);
@@ -223,7 +317,7 @@ class Builder {
         if (delaunay_ > 0) {
             std::priority_queue<Closer> rs;
             for (int i = 0; i < L[0]; ++i) rs.push({dist_(node, L[1 + i]), L[1 + i]});
-            heuristic2(rs, rs.size() - 1);
+            select(rs, rs.size() - 1, node, level);
             L[0] = 0;
             while (!rs.empty()) {
                 L[1 + L[0]] = rs.top().id;
@@ -327,7 +421,7 @@ class Builder {
             if (delaunay_ == 0) {
                 while (rs.size() > (size_t)M_) rs.pop();
             } else {
-                heuristic2(rs, (size_t)M_);
+                select(rs, (size_t)M_, id, level);
             }
             while (!rs.empty()) {
                 ep = rs.top().id;
@@ -342,7 +436,8 @@ class Builder {
         }
     }
 
-    void run(const std::vector<int>& levels, int threads) {
+    // reverse: node 0 first, then n-1, n-2, ..., 1 (the second index of the post-processing, hnsw.cc:262-276)
+    void run(const std::vector<int>& levels, int threads, bool reverse = false) {
         if (n_ == 0) return;
         init_node(0, levels[0]);
         maxlevel_.store(levels[0]);
@@ -352,8 +447,9 @@ class Builder {
             std::vector<uint32_t> vis((size_t)n_ + 1, 0u);
             uint32_t epoch = 0;
             for (;;) {
-                const int id = next.fetch_add(1);
-                if (id >= n_) break;
+                const int pos = next.fetch_add(1);
+                if (pos >= n_) break;
+                const int id = reverse ? n_ - pos : pos;
                 add(id, levels[id], vis, epoch);
             }
         };
@@ -363,6 +459,62 @@ class Builder {
             std::vector<std::thread> th;
             for (int t = 0; t < threads; ++t) th.emplace_back(worker);
             for (auto& t : th) t.join();
+        }
+    }
+
+    // Post-processing (hnsw.cc:251-330): `this` is the second index (built in reverse order), `first` the original one.
+    // Every node but node 0 gets new level-0 friends from the UNION of its friends in both indexes: post = 2 ranks the
+    // union again (delaunay_type 0: the maxM0 closest; 1 and 2: heuristic 1; 3: heuristic 3), farthest first in the list;
+    // post = 1 keeps the whole union in the iteration order of the reference's unordered_set<size_t> (the same libstdc++
+    // container filled in the same order here) and widens maxM0 to the largest union.  The reference runs this loop in
+    // parallel with unguarded reads of lists being replaced; here it runs in order, the reference's at indexThreadQty = 1.
+    void post_process(Builder& first, int post, std::vector<std::vector<int32_t>>& lists0, int& maxM0_out) {
+        size_t maxF = 0;
+        lists0.assign((size_t)n_, {});
+        for (int id = 1; id < n_; ++id) {
+            std::unordered_set<size_t> uni;
+            const int32_t* f1 = links(id, 0);
+            for (int i = 0; i < f1[0]; ++i) uni.insert((size_t)f1[1 + i]);
+            const int32_t* f2 = first.links(id, 0);
+            for (int i = 0; i < f2[0]; ++i) uni.insert((size_t)f2[1 + i]);
+            if (uni.size() > maxF) maxF = uni.size();
+            std::vector<int32_t>& rez = lists0[(size_t)id];
+            if (post == 2) {
+                std::priority_queue<Closer> rs;
+                for (size_t cur : uni) rs.push({dist_((int)cur, id), (int)cur});
+                if (delaunay_ == 0) {
+                    while (rs.size() > (size_t)maxM0_) rs.pop();
+                } else if (delaunay_ == 3) {
+                    heuristic3(rs, (size_t)maxM0_, id, 0);
+                } else {
+                    heuristic1(rs, (size_t)maxM0_);
+                }
+                while (!rs.empty()) {
+                    rez.push_back(rs.top().id);
+                    rs.pop();
+                }
+                int32_t* L = links(id, 0);   // (heuristic 3 of later nodes reads the lists already replaced)
+                L[0] = (int32_t)rez.size();
+                std::memcpy(L + 1, rez.data(), rez.size() * sizeof(int32_t));
+            } else {
+                for (size_t cur : uni) rez.push_back((int32_t)cur);
+            }
+        }
+        const int32_t* L0 = links(0, 0);
+        lists0[0].assign(L0 + 1, L0 + 1 + L0[0]);
+        // post = 1: "maxM0_ = maxF" (hnsw.cc:322); node 0 keeps its list, which the reference's flattened record must hold too
+        maxM0_out = post == 1 ? (int)std::max<size_t>(maxF, (size_t)L0[0]) : maxM0_;
+    }
+
+    // the flattened graph with level-0 lists given from outside (post-processing)
+    void export_graph_lists0(HostGraph& g, const std::vector<std::vector<int32_t>>& lists0, int maxM0) {
+        export_graph(g);
+        g.maxM0 = maxM0;
+        g.links0.assign((size_t)n_ * (maxM0 + 1), 0);
+        for (int i = 0; i < n_; ++i) {
+            int32_t* L = &g.links0[(size_t)i * (maxM0 + 1)];
+            L[0] = (int32_t)lists0[(size_t)i].size();
+            std::memcpy(L + 1, lists0[(size_t)i].data(), lists0[(size_t)i].size() * sizeof(int32_t));
         }
     }
 
@@ -413,9 +565,21 @@ void hnsw_check_params(const HnswBuildParams& bp) {
     // kernels that walk lists in chunks (hnsw_kernels.hip, collect_unvisited_any).  The bound below only keeps sizes sane.
     if (bp.M < 1 || bp.M > 4096 || bp.maxM < 1 || bp.maxM > 4096 || bp.maxM0 < 1 || bp.maxM0 > 8192)
         throw EngineError(Err::IndexBuildFailed, "HNSW: M / maxM must be in [1, 4096] and maxM0 in [1, 8192]");
-    if (bp.delaunay != 0 && bp.delaunay != 2)
-        throw EngineError(Err::IndexBuildFailed, "HNSW: delaunay_type must be 0 or 2 on the GPU engine");
-    if (bp.post != 0) throw EngineError(Err::IndexBuildFailed, "HNSW: post-processing (post=1,2) is not supported");
+    if (bp.delaunay < 0 || bp.delaunay > 3) throw EngineError(Err::IndexBuildFailed, "HNSW: delaunay_type must be 0, 1, 2 or 3");
+    if (bp.post < 0 || bp.post > 2) throw EngineError(Err::IndexBuildFailed, "HNSW: post must be 0, 1 or 2");
+}
+
+// `draws` levels of the one stream (the post-processing's second index keeps drawing from it)
+static std::vector<int32_t> random_level_draws(size_t draws, const HnswBuildParams& bp) {
+    const double mult = bp.mult > 0 ? bp.mult : 1.0 / std::log(1.0 * bp.M);
+    std::mt19937 gen(0);
+    std::uniform_real_distribution<float> uni(0, 1);
+    std::vector<int32_t> levels(draws);
+    for (size_t i = 0; i < draws; ++i) {
+        float r = -std::log(uni(gen)) * mult;
+        levels[i] = (int32_t)r;
+    }
+    return levels;
 }
 
 std::vector<int32_t> hnsw_random_levels(size_t n, const HnswBuildParams& bp) {
@@ -457,7 +621,22 @@ void hnsw_build_host(int space, const void* rows, size_t n, size_t dim, const Hn
     if (threads < 1) threads = 1;
     Builder b(dist, n, bp);
     b.run(levels, threads);
-    b.export_graph(out);
+    if (bp.post == 0 || n == 0) {
+        b.export_graph(out);
+        return;
+    }
+    // post = 1, 2 (hnsw.cc:251-330): the same index once more in reverse order -- node 0 with the stream's next level,
+    // then n-1, ..., 1 -- and new level-0 lists from both
+    const std::vector<int32_t> draws = random_level_draws(2 * n, bp);
+    std::vector<int> levels2(n);
+    levels2[0] = draws[n];
+    for (size_t pos = 1; pos < n; ++pos) levels2[n - pos] = draws[n + pos];
+    Builder b2(dist, n, bp);
+    b2.run(levels2, threads, /*reverse=*/true);
+    std::vector<std::vector<int32_t>> lists0;
+    int maxM0 = bp.maxM0;
+    b2.post_process(b, bp.post, lists0, maxM0);
+    b2.export_graph_lists0(out, lists0, maxM0);
 }
 
 }  // namespace gfxknn
