@@ -1833,20 +1833,45 @@ __global__ __launch_bounds__(NW * 64) void bf_scan_bf16_kernel(BfScanF32Args a) 
     for (int t = 0; t <= kSync && t < nstages; ++t) issue_tile(t);
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
 
-    int foff[8];
+    // LDS address of this lane's fragment of K-step kc in the stage being read (its first block; the second sits 8 KB
+    // behind: an immediate offset of the read).  Moved to the next slot of the ring once per stage -- one VALU per K-step and
+    // stage instead of one address addition per read (round 3: 8 of the ~100 non-MFMA instructions of a stage's block pair).
+    uint32_t vad[8];
 #pragma unroll
-    for (int kc = 0; kc < 8; ++kc) foff[kc] = l31 * 256 + (((kc * 2 + h) ^ (l31 & 15)) * 16);
+    for (int kc = 0; kc < 8; ++kc)
+        vad[kc] = (uint32_t)(uintptr_t)(lptr_t)smem + (uint32_t)(l31 * 256 + (((kc * 2 + h) ^ (l31 & 15)) * 16));
 
     auto score_of = [&](const f32x16& c, int i, const float* ax) __attribute__((always_inline)) -> float {
         if constexpr (MODE == SC_COS) return c[i] * ax[(i & 3) + 8 * (i >> 2)];
         else return c[i];
     };
+    // maximum of a lane's 16 scores: seven v_max3 and a v_max.  (The leaf triples are written out: from nested fmaxf the
+    // compiler folds one leaf into the root and builds its max(c0, c1) with a canonicalising v_max x, x in front of each --
+    // ten instructions where eight do, per check.)
+    auto block_max_leaves = [&](const f32x16& c, const float* ax, float (&m)[5]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            if constexpr (MODE == SC_COS)
+                m[j] = fmaxf(fmaxf(score_of(c, 3 * j, ax), score_of(c, 3 * j + 1, ax)), score_of(c, 3 * j + 2, ax));
+            else
+                asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m[j]) : "v"(c[3 * j]), "v"(c[3 * j + 1]), "v"(c[3 * j + 2]));
+        }
+    };
+    auto block_max_root = [&](const f32x16& c, const float* ax, const float (&m)[5]) __attribute__((always_inline)) -> float {
+        if constexpr (MODE == SC_COS) {
+            return fmaxf(fmaxf(fmaxf(m[0], m[1]), m[2]), fmaxf(fmaxf(m[3], m[4]), score_of(c, 15, ax)));
+        } else {
+            float r0, r1, r;
+            asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r0) : "v"(m[0]), "v"(m[1]), "v"(m[2]));
+            asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r1) : "v"(m[3]), "v"(m[4]), "v"(c[15]));
+            asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(r0), "v"(r1));
+            return r;
+        }
+    };
     auto block_max = [&](const f32x16& c, const float* ax) __attribute__((always_inline)) -> float {
         float m[5];
-#pragma unroll
-        for (int j = 0; j < 5; ++j)
-            m[j] = fmaxf(fmaxf(score_of(c, 3 * j, ax), score_of(c, 3 * j + 1, ax)), score_of(c, 3 * j + 2, ax));
-        return fmaxf(fmaxf(fmaxf(m[0], m[1]), m[2]), fmaxf(fmaxf(m[3], m[4]), score_of(c, 15, ax)));
+        block_max_leaves(c, ax, m);
+        return block_max_root(c, ax, m);
     };
     // (see bf_scan_f32_kernel)
     // does any lane's block maximum reach its threshold?  (a wave-uniform value in a scalar register)
@@ -1911,24 +1936,28 @@ __global__ __launch_bounds__(NW * 64) void bf_scan_bf16_kernel(BfScanF32Args a) 
     float m_pend = 0.f;       // maximum (and trigger) of the group whose branch comes in the next K-step
     unsigned long long trig_pend = 0ull;
     const uint32_t lds0 = (uint32_t)(uintptr_t)(lptr_t)smem;
-    auto load_frag = [&](uint32_t rp, int kc) __attribute__((always_inline)) {
-        const uint32_t ad = rp + foff[kc];
+    // fragment of K-step kc of the current stage's block 0 (OFF = 0) or block 1 (OFF = 8192)
+    auto load_frag = [&](auto off_tag, int kc) __attribute__((always_inline)) {
+        constexpr int OFF = decltype(off_tag)::value;
+        const uint32_t ad = vad[kc];
         if constexpr (NW == 4) {
             switch (kc % 4) {   // (kc is a constant after unrolling)
-                case 0: BF_FRAG_RD("v[224:227]", fh[0], ad); break;
-                case 1: BF_FRAG_RD("v[228:231]", fh[1], ad); break;
-                case 2: BF_FRAG_RD("v[232:235]", fh[2], ad); break;
-                default: BF_FRAG_RD("v[236:239]", fh[3], ad); break;
+                case 0: BF_FRAG_RD_OFF("v[224:227]", fh[0], ad, OFF); break;
+                case 1: BF_FRAG_RD_OFF("v[228:231]", fh[1], ad, OFF); break;
+                case 2: BF_FRAG_RD_OFF("v[232:235]", fh[2], ad, OFF); break;
+                default: BF_FRAG_RD_OFF("v[236:239]", fh[3], ad, OFF); break;
             }
         } else {   // (two waves per SIMD share the register file: stay low)
             switch (kc % 4) {
-                case 0: BF_FRAG_RD("v[96:99]", fh[0], ad); break;
-                case 1: BF_FRAG_RD("v[100:103]", fh[1], ad); break;
-                case 2: BF_FRAG_RD("v[104:107]", fh[2], ad); break;
-                default: BF_FRAG_RD("v[108:111]", fh[3], ad); break;
+                case 0: BF_FRAG_RD_OFF("v[96:99]", fh[0], ad, OFF); break;
+                case 1: BF_FRAG_RD_OFF("v[100:103]", fh[1], ad, OFF); break;
+                case 2: BF_FRAG_RD_OFF("v[104:107]", fh[2], ad, OFF); break;
+                default: BF_FRAG_RD_OFF("v[108:111]", fh[3], ad, OFF); break;
             }
         }
     };
+    using Off0 = std::integral_constant<int, 0>;
+    using Off1 = std::integral_constant<int, 32 * 256>;
     // the counted wait that makes slot kc % 4 (and, with with_init, the start values) valid
     auto wait_frag = [&](auto cnt_tag, int kc, bool with_init) __attribute__((always_inline)) {
         constexpr int N = decltype(cnt_tag)::value;
@@ -1956,8 +1985,25 @@ __global__ __launch_bounds__(NW * 64) void bf_scan_bf16_kernel(BfScanF32Args a) 
         }
         if constexpr (N == 0) { BF_W1("s_waitcnt lgkmcnt(0)") }
         else if constexpr (N == 2) { BF_W1("s_waitcnt lgkmcnt(2)") }
-        else { BF_W1("s_waitcnt lgkmcnt(6)") }
+        else if constexpr (N == 3) { BF_W1("s_waitcnt lgkmcnt(3)") }
+        else if constexpr (N == 6) { BF_W1("s_waitcnt lgkmcnt(6)") }
+        else { static_assert(N == 7, "wait count"); BF_W1("s_waitcnt lgkmcnt(7)") }
 #undef BF_W1
+    };
+    // one MFMA of K-step kc.  A block's first MFMAs take the start values (-|b|^2 / 2, read from LDS into the pinned tuple
+    // `iv`) as their C operand.  Through the builtin the compiler first COPIES the tuple into the accumulator's registers
+    // (8 v_mov_b64 + an s_nop per block); the instruction written out names the pinned registers as C (round 3).
+    auto mfma_step = [&](f32x16& c, const bf16x8& q, int kc, bool first_ch) __attribute__((always_inline)) {
+        if constexpr (MODE == SC_L2) {
+            if (kc == 0 && first_ch) {
+                if constexpr (NW == 4)
+                    asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(c) : "{v[224:227]}"(fh[0]), "a"(q), "{v[240:255]}"(iv));
+                else
+                    asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(c) : "{v[96:99]}"(fh[0]), "a"(q), "{v[112:127]}"(iv));
+                return;
+            }
+        }
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[kc % 4], q, (kc == 0 && first_ch) ? iv : c, 0, 0, 0);
     };
     auto load_init = [&](uint32_t ax) __attribute__((always_inline)) {
         if constexpr (MODE == SC_L2) {
@@ -1972,19 +2018,21 @@ __global__ __launch_bounds__(NW * 64) void bf_scan_bf16_kernel(BfScanF32Args a) 
         }
     };
     constexpr int kInitReads = MODE == SC_L2 ? 4 : 0;
-    const uint32_t ring_a = lds0, aux_a = lds0 + kRing * kStageBytes + 16 * h;
+    const uint32_t aux_a = lds0 + kRing * kStageBytes + 16 * h;
     // (unconditional, also for a split without tiles: a branch here makes `iv` a merge of two values, and the compiler
     //  keeps such merges alive with copies -- of registers whose read is still in flight)
+    // fragment reads run kPre K-steps ahead of their MFMAs (round 3: 3, was 2 -- the four fragment slots allow it: the slot
+    // a read lands in was consumed one step earlier)
+    constexpr int kPre = 3;
     load_init(aux_a);
-    load_frag(ring_a, 0);
-    load_frag(ring_a, 1);
+#pragma unroll
+    for (int kc = 0; kc < kPre; ++kc) load_frag(Off0{}, kc);
     for (int tt = 0; tt < ntiles; ++tt) {
 #pragma unroll
       for (int ch = 0; ch < KCH; ++ch) {
         const int t = tt * KCH + ch;
         constexpr bool kOne = KCH == 1;
         const bool first_ch = kOne || ch == 0, last_ch = kOne || ch == KCH - 1;
-        const uint32_t th_ = ring_a + (t % kRing) * kStageBytes;
         const float* axs = auxr + (t % kAuxRing) * BF_BN + 4 * h;
         const int row0 = r_begin + tt * stage_rows;
 #pragma unroll
@@ -1993,22 +2041,29 @@ __global__ __launch_bounds__(NW * 64) void bf_scan_bf16_kernel(BfScanF32Args a) 
             // starts from the start values iff it runs the tile's first chunk; the block behind it likewise
             const bool prev_final = blk == 1 ? last_ch : first_ch;
             const bool init_next = blk == 0 ? first_ch : last_ch;
-            const uint32_t rp = th_ + blk * 32 * 256;
-            const uint32_t nrp = blk == 0 ? th_ + 32 * 256 : ring_a + ((t + 1) % kRing) * kStageBytes;
+            // (block 1's last two K-steps prefetch from the NEXT stage's slot: the addresses move there one by one)
+            const int dslot = ((t + 1) % kRing == 0) ? -(kRing - 1) * kStageBytes : kStageBytes;
             const uint32_t nax = blk == 0 ? aux_a + ((t % kAuxRing) * BF_BN + 32) * 4 : aux_a + (((t + 1) % kAuxRing) * BF_BN) * 4;
 #pragma unroll
             for (int kc = 0; kc < 8; ++kc) {
-                // the read of step kc+2, then the wait for step kc's fragment: at most the reads of steps kc+1, kc+2 (and
-                // the next block's start values) stay in flight
-                if (kc + 2 < 8) {
-                    load_frag(rp, kc + 2);
-                    wait_frag(std::integral_constant<int, 2>{}, kc, kc == 0 && MODE == SC_L2 && first_ch);
+                // the read of step kc+kPre, then the wait for step kc's fragment: at most the reads of steps kc+1 .. kc+kPre
+                // (and the next block's start values) stay in flight
+                if (kc + kPre < 8) {
+                    if (blk == 0) load_frag(Off0{}, kc + kPre);
+                    else load_frag(Off1{}, kc + kPre);
+                    wait_frag(std::integral_constant<int, kPre>{}, kc, kc == 0 && MODE == SC_L2 && first_ch);
                 } else {
                     // (also in the very last block: see bf_scan_f32_kernel)
                     if (kc == 6 && init_next) load_init(nax);
-                    load_frag(nrp, kc + 2 - 8);
-                    if (kInitReads && init_next) wait_frag(std::integral_constant<int, 6>{}, kc, false);
-                    else wait_frag(std::integral_constant<int, 2>{}, kc, false);
+                    if (blk == 0) {
+                        load_frag(Off1{}, kc + kPre - 8);
+                    } else {
+                        vad[kc + kPre - 8] += (uint32_t)dslot;
+                        load_frag(Off0{}, kc + kPre - 8);
+                    }
+                    // (from K-step 6 on the next block's four start-value reads are in flight too, older than the last read)
+                    if (kInitReads && init_next && kc >= 6) wait_frag(std::integral_constant<int, kPre + 4>{}, kc, false);
+                    else wait_frag(std::integral_constant<int, kPre>{}, kc, false);
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 // The previous block's scores are checked one group per kEvery K-steps, in two halves: step gc * kEvery
@@ -2021,9 +2076,22 @@ __global__ __launch_bounds__(NW * 64) void bf_scan_bf16_kernel(BfScanF32Args a) 
                 const int gc = kc / kEvery;
                 const bool chk = prev_final && (kc % kEvery) == 0, br = prev_final && (kc % kEvery) == 1;
                 float m = 0.f;
-                if (chk) m = block_max(acc[blk ^ 1][gc], pv_ax);   // (also before the first block: no branch between the MFMAs)
-                acc[blk][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[kc % 4], qh[0][8 * ch + kc], (kc == 0 && first_ch) ? iv : acc[blk][0], 0, 0, 0);
-                if (br) {
+                // (the written-out MFMAs of a block's first K-step are invisible to sched_group_barrier: there the check's
+                //  VALU work is placed by hand -- leaves under the first MFMA, root under the second)
+                const bool by_hand = MODE == SC_L2 && kc == 0 && first_ch && chk && QG == 2;
+                float m5[5];
+                if (chk && !by_hand) m = block_max(acc[blk ^ 1][gc], pv_ax);   // (also before the first block: no branch between the MFMAs)
+                mfma_step(acc[blk][0], qh[0][8 * ch + kc], kc, first_ch);
+                if (by_hand) {
+                    if constexpr (QG == 2) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        block_max_leaves(acc[blk ^ 1][gc], pv_ax, m5);
+                        __builtin_amdgcn_sched_barrier(0);
+                        mfma_step(acc[blk][1], qh[1][8 * ch + kc], kc, first_ch);
+                        __builtin_amdgcn_sched_barrier(0);
+                        m = block_max_root(acc[blk ^ 1][gc], pv_ax, m5);
+                    }
+                } else if (br) {
                     __builtin_amdgcn_sched_barrier(0);
                     finish_check(trig_pend, m_pend, acc[blk ^ 1][gc], gc, pv_ax, pv_row0);
                     __builtin_amdgcn_sched_barrier(0);
@@ -2033,7 +2101,8 @@ __global__ __launch_bounds__(NW * 64) void bf_scan_bf16_kernel(BfScanF32Args a) 
                 }
 #pragma unroll
                 for (int g = 1; g < QG; ++g) {
-                    acc[blk][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[kc % 4], qh[g][8 * ch + kc], (kc == 0 && first_ch) ? iv : acc[blk][g], 0, 0, 0);
+                    if (by_hand) break;
+                    mfma_step(acc[blk][g], qh[g][8 * ch + kc], kc, first_ch);
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                     __builtin_amdgcn_sched_group_barrier(0x002, 12 / QG, 0);
                 }
@@ -2053,6 +2122,10 @@ __global__ __launch_bounds__(NW * 64) void bf_scan_bf16_kernel(BfScanF32Args a) 
                 pv_ax = axs + blk * 32;
                 pv_row0 = row0 + blk * 32;
                 have_pv = true;
+            }
+            if (blk == 1) {
+#pragma unroll
+                for (int kc = kPre; kc < 8; ++kc) vad[kc] += (uint32_t)dslot;
             }
             if (blk == 0) {
                 // every kSync stages: the next kSync stages (requested at the last meeting) must have landed; behind the
@@ -2189,7 +2262,7 @@ __global__ __launch_bounds__(256) void bf_f32_threshold_kernel(const float* top8
     const uint32_t T = total >= r ? wave_rth_largest_u32<NPER>(key, r) : 0u;
     const float t3 = total >= r ? ord_f32(T) : -INFINITY;   // s^_r
     float t1 = t3;
-    bool ok = !force_precise;
+    bool ok = force_precise != 1;
     if (ok && t3 > -INFINITY) {
         const float need = 2.1f * e1;
         uint32_t best = 0u;     // largest key at or below s^_r whose value is at least `need` below it (0: none)
@@ -2219,7 +2292,7 @@ __global__ __launch_bounds__(256) void bf_f32_threshold_kernel(const float* top8
     }
     if (lane == 0) {
         thr3[q] = t3 - 1.02f * e1;
-        thr1[q] = t1;
+        thr1[q] = force_precise == 2 ? INFINITY : t1;   // (2: NMSLIB_GPU_DEBUG & 8192 -- a scan without hits, timing experiments)
         if (!ok) atomicOr(&precise[q / group_q], 1);
     }
 }
@@ -3745,11 +3818,12 @@ hipError_t launch_bf_f32_fast(const BfF32Fast& f, int space, int n, int dim, int
     if (e != hipSuccess) return e;
     // (fallback flags + precise flags: cleared by the prep kernel)
     {
+        static const bool dbg_nohit = getenv("NMSLIB_GPU_DEBUG") && (atoi(getenv("NMSLIB_GPU_DEBUG")) & 8192);
         const int depth = f.rcap <= 64 && f.s_nsplit >= 32 ? 4 : 8;
         const dim3 tgrid((f.qpad + 3) / 4);
 #define BF_THR_ARGS                                                                                                               \
     top8, 2 * f.s_nsplit, depth, f.r, f.rcap, nq, f.qpad, queries_sel, sld, sdim, f.mode == 2 ? 1.0f : bmax, bres, f.tq,          \
-        f.force_precise ? 1 : 0, thr, thr1, precise
+        f.force_precise ? 1 : (dbg_nohit ? 2 : 0), thr, thr1, precise
         if (2 * f.s_nsplit * depth <= 512) hipLaunchKernelGGL(bf_f32_threshold_kernel<8>, tgrid, dim3(256), 0, s, BF_THR_ARGS);
         else hipLaunchKernelGGL(bf_f32_threshold_kernel<16>, tgrid, dim3(256), 0, s, BF_THR_ARGS);   // (s_nsplit <= 64)
 #undef BF_THR_ARGS

@@ -24,6 +24,9 @@ PMC_SETS = {
     "sq3": "SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR",
     "sq4": "SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_SALU SQ_WAIT_INST_ANY SQ_WAVE_CYCLES",
     "grbm": "GRBM_GUI_ACTIVE",
+    "ldslat": "LdsLatency",
+    "vmemlat": "VmemLatency",
+    "sq5": "SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_LDS_DATA_FIFO_FULL SQ_LDS_CMD_FIFO_FULL SQ_LDS_ADDR_CONFLICT",
     "fetch": "FETCH_SIZE",
     "write": "WRITE_SIZE",
 }
@@ -44,11 +47,22 @@ def main():
         del args[i:i + 2]
     if "--workload" in args:
         workload = args[args.index("--workload") + 1]
+    only_sets = None          # --sets a,b: only these counter passes (and no kernel trace) -> <tag>_<workload>_pmc.json
+    if "--sets" in args:
+        i = args.index("--sets")
+        only_sets = args[i + 1].split(",")
+        del args[i:i + 2]
     bench = ["python3", os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "3", "--no-cpu-baseline"] + args
     out = os.path.join(ROOT, "gpurun_out", "prof")
     os.makedirs(out, exist_ok=True)
     env = dict(os.environ, TMPDIR="/tmp")
 
+    if only_sets is None:
+        trace_pass(tag, workload, bench, out, env)
+    counter_passes(tag, workload, bench, out, env, only_sets)
+
+
+def trace_pass(tag, workload, bench, out, env):
     # ---- pass 0: kernel trace + stats ----
     d = os.path.join(out, f"{tag}_{workload}_trace")
     rc, log = run(["rocprofv3", "--kernel-trace", "--stats", "-d", d, "-o", "t", "--output-format", "csv", "--"] + bench, env)
@@ -88,10 +102,16 @@ def main():
     for f in glob.glob(os.path.join(trace_dir, "**", "*kernel_stats.csv"), recursive=True):
         shutil.copy(f, os.path.join(out, f"{tag}_{workload}_rocprofv3_kernel_stats.csv"))
     shutil.rmtree(trace_dir, ignore_errors=True)
+    for k, e in list(stats["per_kernel"].items())[:6]:
+        print(f"{e['timed_avg_us']:>10.1f} us (timed avg) x{e['calls']:<4d} vgpr={e['vgpr']}  {k[:100]}")
 
+
+def counter_passes(tag, workload, bench, out, env, only_sets):
     # ---- counter passes ----
     pmc = {}
     for name, counters in PMC_SETS.items():
+        if only_sets is not None and name not in only_sets:
+            continue
         d = os.path.join(out, f"{tag}_{workload}_pmc_{name}")
         rc, log = run(["rocprofv3", "--pmc"] + counters.split() + ["-d", d, "-o", "c", "--output-format", "csv", "--"] + bench, env)
         agg = {}
@@ -112,13 +132,15 @@ def main():
             pmc.setdefault("_errors", {})[name] = log[-2000:]
     json.dump(pmc, open(os.path.join(out, f"{tag}_{workload}_pmc.json"), "w"), indent=1)
     # brief console summary
-    for k, e in list(stats["per_kernel"].items())[:6]:
-        print(f"{e['timed_avg_us']:>10.1f} us (timed avg) x{e['calls']:<4d} vgpr={e['vgpr']}  {k[:100]}")
     for k, cs in pmc.items():
         if ("hnsw_search" in k or "bf_scan" in k) and cs.get("SQ_WAVES", {}).get("dispatches", 0) >= 15:
             print(k[:90], {c: round(v["per_dispatch"], 1) for c, v in cs.items() if c in
                            ("SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_ANY",
                             "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_MFMA", "FETCH_SIZE", "WRITE_SIZE", "GRBM_GUI_ACTIVE")})
+    if only_sets is not None:
+        for k, cs in pmc.items():
+            if "bf_scan" in k or "hnsw_search" in k or "rerank" in k:
+                print(k[:100], {c: round(v["per_dispatch"], 1) for c, v in cs.items()})
 
 
 if __name__ == "__main__":
