@@ -1064,21 +1064,33 @@ __global__ __launch_bounds__(256, 2) void bf_scan_u8_kernel(BfScanArgs a) {
     const int r_begin = split * a.tps * tstr * BF_BN;
     const int stage_rows = tstr * BF_BN;
 
+    // LDS-DMA in the scalar-base form (see bf_scan_bf16_kernel's issue_tile: the lane's constant byte offset in a VGPR, the
+    // stage's base in an SGPR pair, M0 from scalars; every wave requests all 64 aux values, one instruction, no exec mask)
     const int dma_row = lane >> 3;
+    uint32_t dma_voff[2];
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+        const int row = 8 * (2 * wave + jj) + dma_row;
+        dma_voff[jj] = (uint32_t)(row * 128 + ((lane & 7) ^ ((row >> 1) & 7)) * 16);
+    }
+    const uint32_t dma_lds0 = (uint32_t)(uintptr_t)(lptr_t)ring + (uint32_t)(2 * __builtin_amdgcn_readfirstlane(wave) * 1024);
+    const uint32_t aux_lds0 = (uint32_t)(uintptr_t)(lptr_t)auxr;
+    const uint32_t aux_voff = (uint32_t)lane * 4u;
     auto issue_tile = [&](int stage) __attribute__((always_inline)) {
         const int slot = stage % kRing;
         const int row0 = r_begin + stage * stage_rows;
+        const unsigned long long sbase = (unsigned long long)(uintptr_t)a.base_i8 + (unsigned long long)row0 * 128ull;
+        const uint32_t m0v = dma_lds0 + (uint32_t)slot * kTileBytes;
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
 #pragma unroll
-        for (int jj = 0; jj < 2; ++jj) {
-            const int j = 2 * wave + jj;
-            const int row = 8 * j + dma_row;
-            const int c = (lane & 7) ^ ((row >> 1) & 7);
-            const uint8_t* src = a.base_i8 + (size_t)(row0 + row) * 128 + c * 16;
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(ring + slot * kTileBytes + j * 1024), 16, 0, 0);
-        }
-        if (lane < 16)
-            __builtin_amdgcn_global_load_lds((gptr_t)(a.auxh + row0 + 16 * wave + lane),
-                                             (lptr_t)(auxr + (stage % kAuxRing) * BF_BN + 16 * wave), 4, 0, 0);
+        for (int jj = 0; jj < 2; ++jj)
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                         :: "v"(dma_voff[jj]), "s"(sbase), "s"(m0v + (uint32_t)jj * 1024u) : "memory", "m0");
+        const unsigned long long abase = (unsigned long long)(uintptr_t)a.auxh + (unsigned long long)row0 * 4ull;
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1"
+                     :: "v"(aux_voff), "s"(abase), "s"(aux_lds0 + (uint32_t)((stage % kAuxRing) * BF_BN * 4)) : "memory", "m0");
+#pragma clang diagnostic pop
     };
 
     // this lane's QG queries, their thresholds, their lists (each lane owns the rows of its half h: no atomics)
@@ -1789,21 +1801,38 @@ __global__ __launch_bounds__(NW * 64) void bf_scan_bf16_kernel(BfScanF32Args a) 
     const int r_begin = split * a.tps * tstr * BF_BN;
     const int stage_rows = tstr * BF_BN;
 
-    // one stage = 16 DMA pieces of 1 KiB (4 rows x 256 B): wave w issues pieces 4w .. 4w+3 and 16 of the 64 aux values
+    // one stage = 16 DMA pieces of 1 KiB (4 rows x 256 B): wave w issues pieces (16/NW) w .. and the stage's 64 aux values.
+    // Written out in the scalar-base form (round 3): `global_load_lds_dwordx4 voff, s[base]` with the lane's constant byte
+    // offset in a VGPR and the stage's base in an SGPR pair -- through the builtin every piece cost a 64-bit address sum per
+    // lane, a v_readfirstlane for M0 and an exec-masked tail for the aux values, ~45 instructions per stage issued by all
+    // eight waves in one burst behind each barrier.  Every wave requests all 64 aux values (one instruction, no exec mask;
+    // the waves write the same bytes).
+    uint32_t dma_voff[16 / NW];
+#pragma unroll
+    for (int jj = 0; jj < 16 / NW; ++jj) {
+        const int pj = (16 / NW) * wave + jj;
+        const int row = 4 * pj + (lane >> 4);
+        const int c = (lane & 15) ^ (row & 15);
+        dma_voff[jj] = (uint32_t)((row * kDp + c * 8) * 2);
+    }
+    const uint32_t dma_lds0 = (uint32_t)(uintptr_t)(lptr_t)ring + (uint32_t)((16 / NW) * __builtin_amdgcn_readfirstlane(wave) * 1024);   // (a scalar: it goes to M0)
+    const uint32_t aux_lds0 = (uint32_t)(uintptr_t)(lptr_t)auxr;
+    const uint32_t aux_voff = (uint32_t)lane * 4u;
     auto issue_tile = [&](int stage) __attribute__((always_inline)) {
         const int slot = stage % kRing;
         const int row0 = r_begin + (stage / KCH) * stage_rows;
+        const unsigned long long sbase = (unsigned long long)(uintptr_t)a.base_hi + ((unsigned long long)row0 * kDp + (stage % KCH) * 128) * 2ull;
+        const uint32_t m0v = dma_lds0 + (uint32_t)slot * kStageBytes;
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
 #pragma unroll
-        for (int jj = 0; jj < 16 / NW; ++jj) {
-            const int pj = (16 / NW) * wave + jj;
-            const int row = 4 * pj + (lane >> 4);
-            const int c = (lane & 15) ^ (row & 15);
-            const __bf16* src = a.base_hi + (size_t)(row0 + row) * kDp + (stage % KCH) * 128 + c * 8;
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(ring + slot * kStageBytes + pj * 1024), 16, 0, 0);
-        }
-        if (lane < 64 / NW)
-            __builtin_amdgcn_global_load_lds((gptr_t)(a.auxp + row0 + (64 / NW) * wave + lane),
-                                             (lptr_t)(auxr + (stage % kAuxRing) * BF_BN + (64 / NW) * wave), 4, 0, 0);
+        for (int jj = 0; jj < 16 / NW; ++jj)
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                         :: "v"(dma_voff[jj]), "s"(sbase), "s"(m0v + (uint32_t)jj * 1024u) : "memory", "m0");
+        const unsigned long long abase = (unsigned long long)(uintptr_t)a.auxp + (unsigned long long)row0 * 4ull;
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1"
+                     :: "v"(aux_voff), "s"(abase), "s"(aux_lds0 + (uint32_t)((stage % kAuxRing) * BF_BN * 4)) : "memory", "m0");
+#pragma clang diagnostic pop
     };
 
     bf16x8 qh[QG][8 * KCH];
