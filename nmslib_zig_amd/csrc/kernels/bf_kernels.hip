@@ -967,9 +967,23 @@ __global__ __launch_bounds__(256, 2) void bf_select_u8_kernel(BfArgsU8 a) {
 // (score >= t  <=>  score - t is not negative, for all finite values and for infinite scores against finite thresholds;
 //  inf - inf = NaN may add a spurious candidate, never lose one.)
 __device__ __forceinline__ uint32_t hit_mask_f32(const f32x16& c, float t) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
     uint32_t m = 0u;
+    const f32x2 tt = {t, t};
+    // (one v_pk_add_f32 for two scores -- the accumulators are register pairs --, four of them ahead of their eight
+    //  v_alignbit: a packed result read by the very next instruction costs a wait state)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) m = __builtin_amdgcn_alignbit(m, __float_as_uint(c[i] - t), 31);   // (m << 1) | sign
+    for (int i0 = 0; i0 < 16; i0 += 8) {
+        f32x2 d[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) d[j] = f32x2{c[i0 + 2 * j], c[i0 + 2 * j + 1]} - tt;
+        asm volatile("" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            m = __builtin_amdgcn_alignbit(m, __float_as_uint(d[j][0]), 31);   // (m << 1) | sign
+            m = __builtin_amdgcn_alignbit(m, __float_as_uint(d[j][1]), 31);
+        }
+    }
     return ~m & 0xffffu;
 }
 __device__ __forceinline__ uint32_t hit_mask_i32(const i32x16& c, int t) {
@@ -1474,23 +1488,38 @@ __global__ __launch_bounds__(256) void bf_scan_f32_kernel(BfScanF32Args a) {
 
     // one stage = 32 DMA pieces of 1 KiB (4 rows x 256 B; 0..15 hi tile, 16..31 lo tile): wave w issues pieces
     // kPieces * w .. + kPieces - 1, and its share of the stage's 64 aux values
-    constexpr int kPieces = 32 / NW, kAuxLanes = BF_BN / NW;
+    // (scalar-base LDS-DMA, see bf_scan_bf16_kernel's issue_tile; NW = 4: wave w issues pieces 8w .. 8w+7, all of one
+    //  half -- hi tile for waves 0 and 1, lo tile for 2 and 3)
+    constexpr int kPieces = 32 / NW;
+    static_assert(kPieces == 8, "a wave's pieces lie in one half of the stage");
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    uint32_t dma_voff[kPieces];
+#pragma unroll
+    for (int jj = 0; jj < kPieces; ++jj) {
+        const int pj = (kPieces * wave + jj) & 15;     // piece pj of its tile = rows 4*pj .. 4*pj+3
+        const int row = 4 * pj + (lane >> 4);
+        dma_voff[jj] = (uint32_t)((row * 128 + ((lane & 15) ^ (row & 15)) * 8) * 2);
+    }
+    const int dma_half = (kPieces * wave_u) >> 4;
+    const uint32_t dma_lds0 = (uint32_t)(uintptr_t)(lptr_t)ring + (uint32_t)(dma_half * kHalfBytes + ((kPieces * wave_u) & 15) * 1024);
+    const unsigned long long dma_src0 = (unsigned long long)(uintptr_t)(dma_half ? a.base_lo : a.base_hi);
+    const uint32_t aux_lds0 = (uint32_t)(uintptr_t)(lptr_t)auxr;
+    const uint32_t aux_voff = (uint32_t)lane * 4u;
     auto issue_tile = [&](int stage) __attribute__((always_inline)) {
         const int slot = stage % kRing;
         const int row0 = r_begin + stage * stage_rows;
+        const unsigned long long sbase = dma_src0 + (unsigned long long)row0 * 256ull;
+        const uint32_t m0v = dma_lds0 + (uint32_t)slot * kStageBytes;
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
 #pragma unroll
-        for (int jj = 0; jj < kPieces; ++jj) {
-            const int j = kPieces * wave + jj;
-            const int half = j >> 4, pj = j & 15;     // piece pj of its tile = rows 4*pj .. 4*pj+3
-            const int row = 4 * pj + (lane >> 4);
-            const int c = (lane & 15) ^ (row & 15);
-            const __bf16* src = (half ? a.base_lo : a.base_hi) + (size_t)(row0 + row) * 128 + c * 8;
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(ring + slot * kStageBytes + half * kHalfBytes + pj * 1024),
-                                             16, 0, 0);
-        }
-        if (lane < kAuxLanes)
-            __builtin_amdgcn_global_load_lds((gptr_t)(a.auxp + row0 + kAuxLanes * wave + lane),
-                                             (lptr_t)(auxr + (stage % kAuxRing) * BF_BN + kAuxLanes * wave), 4, 0, 0);
+        for (int jj = 0; jj < kPieces; ++jj)
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                         :: "v"(dma_voff[jj]), "s"(sbase), "s"(m0v + (uint32_t)jj * 1024u) : "memory", "m0");
+        const unsigned long long abase = (unsigned long long)(uintptr_t)a.auxp + (unsigned long long)row0 * 4ull;
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1"
+                     :: "v"(aux_voff), "s"(abase), "s"(aux_lds0 + (uint32_t)((stage % kAuxRing) * BF_BN * 4)) : "memory", "m0");
+#pragma clang diagnostic pop
     };
 
     // this lane's QG queries: fragments of both halves; lane (l31, h) holds elements 16*kc + 8*h + {0..7}
