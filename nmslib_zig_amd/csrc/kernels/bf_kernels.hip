@@ -2082,6 +2082,13 @@ __global__ __launch_bounds__(NW * 64) void bf_scan_bf16_kernel(BfScanF32Args a) 
     // fragment reads run kPre K-steps ahead of their MFMAs (round 3: 3, was 2 -- the four fragment slots allow it: the slot
     // a read lands in was consumed one step earlier)
     constexpr int kPre = 3;
+    // The two waves of a SIMD (w and w + 4) run the same program and meet at every barrier: in lockstep they reach their
+    // MFMA pairs and their check's VALU work together.  Waves 4..7 check the previous block two K-steps later (stagger:
+    // MI355X_MICROARCH.md, "Two waves per SIMD", item 9) -- same instructions, same results, other K-steps.
+    // (Each copy of the loop carries its own prologue reads and its own final wait: a pinned fragment register alive across
+    //  the branch between the copies is merged with COPIES of registers whose reads are in flight -- tests/test_isa_audit.py.)
+    auto main_loop = [&](auto stag_tag) __attribute__((always_inline)) {
+    constexpr int kStag = decltype(stag_tag)::value;
     load_init(aux_a);
 #pragma unroll
     for (int kc = 0; kc < kPre; ++kc) load_frag(Off0{}, kc);
@@ -2131,8 +2138,9 @@ __global__ __launch_bounds__(NW * 64) void bf_scan_bf16_kernel(BfScanF32Args a) 
                 // waits for the VALU chain that waited for the step's last MFMA to issue; measured 252 vs 129 clocks
                 // per K-step).
                 constexpr int kEvery = 8 / QG;
-                const int gc = kc / kEvery;
-                const bool chk = prev_final && (kc % kEvery) == 0, br = prev_final && (kc % kEvery) == 1;
+                const int gc = kc >= kStag ? (kc - kStag) / kEvery : 0;
+                const bool chk = prev_final && kc >= kStag && ((kc - kStag) % kEvery) == 0;
+                const bool br = prev_final && kc >= kStag && ((kc - kStag) % kEvery) == 1;
                 float m = 0.f;
                 // (the written-out MFMAs of a block's first K-step are invisible to sched_group_barrier: there the check's
                 //  VALU work is placed by hand -- leaves under the first MFMA, root under the second)
@@ -2198,6 +2206,13 @@ __global__ __launch_bounds__(NW * 64) void bf_scan_bf16_kernel(BfScanF32Args a) 
     }
     // (the prefetches the last block issued for a block that does not exist: their registers are free only now)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    };
+    if constexpr (NW == 8) {
+        if (__builtin_amdgcn_readfirstlane(wave) >= 4) main_loop(std::integral_constant<int, 2>{});
+        else main_loop(std::integral_constant<int, 0>{});
+    } else {
+        main_loop(std::integral_constant<int, 0>{});
+    }
     if (have_pv) {   // the last block (nstages > 0: it was block 1 of its stage)
 #pragma unroll
         for (int g = 0; g < QG; ++g) {
