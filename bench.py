@@ -384,7 +384,7 @@ def run_workload(a, name, cx):
         one = tiles > 0 and precise == 0
         roof = {"bound": "mfma", "achieved": round(flops / kern_s / 1e12, 2), "peak": PEAK_BF16_MFMA_TFLOPS,
                 "unit": "TFLOP/s", "kernel": "bf_scan_bf16_kernel" if one else "bf_scan_f32_kernel",
-                "arithmetic": ("one bf16 product per element (q_hi . b_hi, f32 accumulate) under a per-query error bound, "
+                "arithmetic": ("one fp16 product per element (fp16(s q) . fp16(s b), f32 accumulate) under a per-query error bound, "
                                if one else
                                "bf16 x 3 (f32 rows and queries split into hi + lo bf16; qh.bh + qh.bl + ql.bh, f32 accumulate), ")
                               + "proof + exact f32 re-rank",
@@ -442,7 +442,7 @@ def run_workload(a, name, cx):
         "higher_is_better": True,
         "scaling": "weak" if sharded_gen else "strong",
         "vs_baseline": None,
-        "dtype": "u8" if u8 else (("bf16+f32" if stats.get("fast_tiles_precise", 0) == 0 and stats.get("fast_tiles", 0) else "bf16x3+f32")
+        "dtype": "u8" if u8 else (("f16+f32" if stats.get("fast_tiles_precise", 0) == 0 and stats.get("fast_tiles", 0) else "bf16x3+f32")
                                   if last_path == 1 else "f32"),
         "data": "synthetic",
         "config": {

@@ -775,13 +775,9 @@ void Engine::finalize() {
             // largest norm (and bf16 rounding residual) of the selection rows: the error bounds of the selection scores
             // (proofs in bf_rerank_kernel and bf_rerank_f32_list_kernel)
             {
-                DevBuf d_bm;
-                d_bm.ensure(16);
                 const bool cosine = space_ == SP_COSINE || space_ == SP_ANGULAR;
-                float bm[2] = {0.f, 0.f};
-                hip_check(launch_row_maxnorm(sel_rows, (int)n, ldb_, (int)dim_, cosine, d_bm.as<float>(), stream_), "row norms");
-                hip_check(hipMemcpyAsync(bm, d_bm.ptr(), 8, hipMemcpyDeviceToHost, stream_), "bmax");
-                hip_check(hipStreamSynchronize(stream_), "row norms");
+                float bm[4] = {0.f, 0.f, 0.f, 0.f};
+                measure_rows_f16(sel_rows, n, ldb_, (int)dim_, cosine, bm);
                 bmax_ = bm[0];
                 bres_ = bm[1];
             }
@@ -789,7 +785,9 @@ void Engine::finalize() {
             have_bf16_ = false;
             d_bf_hi_.release();
             d_bf_lo_.release();
+            d_f16_hi_.release();
             d_auxp_.release();
+            d_auxp16_.release();
             const bool cosine_space = space_ == SP_COSINE || space_ == SP_ANGULAR;
             const bool fast_space = space_ == SP_L2 || space_ == SP_NEGDOT || (cosine_space && !centred_);
             if (cosine_space && centred_ && dim_ + 3 <= 1024 && n >= 65536) {
@@ -809,21 +807,30 @@ void Engine::finalize() {
                     hip_check(launch_row_aug_cosc(d_rows_.as<float>(), sel_rows, (int)n, ldb_, (int)dim_, mu_norm_, cosc_lambda_,
                                                   d_aug.as<float>(), (int)dp, d_flag.as<int>(), stream_),
                               "augmented rows");
-                    hip_check(launch_row_maxnorm(d_aug.as<float>(), (int)n, (int)dp, (int)dim_ + 3, false, d_flag.as<float>() + 1,
-                                                 stream_),
-                              "augmented row norms");
-                    int fl[3] = {0, 0, 0};
-                    hip_check(hipMemcpyAsync(fl, d_flag.ptr(), 12, hipMemcpyDeviceToHost, stream_), "flags");
+                    int fl[1] = {0};
+                    hip_check(hipMemcpyAsync(fl, d_flag.ptr(), 4, hipMemcpyDeviceToHost, stream_), "flags");
                     hip_check(hipStreamSynchronize(stream_), "augmented rows");
                     if (fl[0] == 0) {
-                        std::memcpy(&bmax_c_, &fl[1], 4);
-                        std::memcpy(&bres_c_, &fl[2], 4);
-                        d_bf_hi_.ensure(n_pad * dp * 2);
-                        if (dp == 128) d_bf_lo_.ensure(n_pad * 128 * 2);
+                        float bm[4] = {0.f, 0.f, 0.f, 0.f};
+                        measure_rows_f16(d_aug.as<float>(), n, (int)dp, (int)dim_ + 3, false, bm);   // (sets f16_scale_, bres16_)
+                        // (the augmented rows are divided by their norm ~ |mean|, the augmented queries are not)
+                        if (mu_norm_ > 0) {
+                            const int eq = std::max(-40, std::min(40, (int)std::lround(std::log2((double)f16_scale_) - std::log2(mu_norm_))));
+                            f16_scale_q_ = std::ldexp(1.f, eq);
+                        }
+                        bmax_c_ = bm[0];
+                        bres_c_ = bm[1];
+                        if (dp == 128) {
+                            d_bf_hi_.ensure(n_pad * dp * 2);
+                            d_bf_lo_.ensure(n_pad * 128 * 2);
+                        }
+                        d_f16_hi_.ensure(n_pad * dp * 2);
                         d_auxp_.ensure(n_pad * 4);
-                        hip_check(launch_split_bf16(d_aug.as<float>(), (int)n, (int)n_pad, (int)dp, (int)dim_ + 3, d_bf_hi_.ptr(),
-                                                    dp == 128 ? d_bf_lo_.ptr() : nullptr, nullptr, 0.f, d_auxp_.as<float>(),
-                                                    stream_, (int)dp),
+                        d_auxp16_.ensure(n_pad * 4);
+                        hip_check(launch_split_bf16(d_aug.as<float>(), (int)n, (int)n_pad, (int)dp, (int)dim_ + 3,
+                                                    dp == 128 ? d_bf_hi_.ptr() : nullptr, dp == 128 ? d_bf_lo_.ptr() : nullptr,
+                                                    nullptr, 0.f, d_auxp_.as<float>(), stream_, (int)dp, d_f16_hi_.ptr(), f16_scale_,
+                                                    d_auxp16_.as<float>(), 1.f),
                                   "split rows");
                         hip_check(hipStreamSynchronize(stream_), "split rows");   // (d_aug goes out of scope)
                         have_bf16_ = true;
@@ -836,14 +843,21 @@ void Engine::finalize() {
                 const BfF32Fast f0 = bf_f32_fast_plan((int)n, (int)dim_, 1024, 10, space_, centred_);
                 const size_t dp = f0.use ? (size_t)f0.dp : 128;
                 const size_t n_pad = (size_t)bf_f32_rows_padded((int)n);
-                d_bf_hi_.ensure(n_pad * dp * 2);
-                if (dp == 128) d_bf_lo_.ensure(n_pad * 128 * 2);
+                // (bf16 hi / lo tiles: the split-product scan, rows of up to 128 dimensions only; fp16 tiles of the rows times
+                //  f16_scale_: the one-product scan -- its start values in units of scale^2 for l2, the plain 1/|b| for cosine)
+                if (dp == 128) {
+                    d_bf_hi_.ensure(n_pad * dp * 2);
+                    d_bf_lo_.ensure(n_pad * 128 * 2);
+                }
+                d_f16_hi_.ensure(n_pad * dp * 2);
                 d_auxp_.ensure(n_pad * 4);
+                d_auxp16_.ensure(n_pad * 4);
                 const float pad = space_ == SP_L2 ? -INFINITY : 0.f;
-                hip_check(launch_split_bf16(sel_rows, (int)n, (int)n_pad, ldb_, (int)dim_, d_bf_hi_.ptr(),
+                hip_check(launch_split_bf16(sel_rows, (int)n, (int)n_pad, ldb_, (int)dim_, dp == 128 ? d_bf_hi_.ptr() : nullptr,
                                             dp == 128 ? d_bf_lo_.ptr() : nullptr,
                                             space_ == SP_NEGDOT ? nullptr : d_aux_.as<float>(), pad, d_auxp_.as<float>(),
-                                            stream_, (int)dp),
+                                            stream_, (int)dp, d_f16_hi_.ptr(), f16_scale_, d_auxp16_.as<float>(),
+                                            space_ == SP_L2 ? f16_scale_ * f16_scale_ : 1.f),
                           "split rows");
                 have_bf16_ = true;
             }
@@ -853,6 +867,30 @@ void Engine::finalize() {
         upload_graph();
     }
     dirty_ = false;
+}
+
+// bm[0] largest row norm, bm[1] largest bf16 residual; chooses the fp16 scale of the one-product scan from the largest
+// |element| (a power of two that puts it into [2^13, 2^14): a factor 4 of headroom below fp16's 65504 for the queries) and
+// measures the rows' largest fp16 residual at that scale (f16_scale_, bres16_)
+void Engine::measure_rows_f16(const float* rows, size_t n, int ld, int dim, bool relative, float* bm) {
+    DevBuf d_bm;
+    d_bm.ensure(16);
+    hip_check(launch_row_maxnorm(rows, (int)n, ld, dim, relative, d_bm.as<float>(), stream_), "row norms");
+    hip_check(hipMemcpyAsync(bm, d_bm.ptr(), 16, hipMemcpyDeviceToHost, stream_), "bmax");
+    hip_check(hipStreamSynchronize(stream_), "row norms");
+    f16_scale_ = 1.f;
+    if (bm[2] > 0.f && std::isfinite(bm[2])) {
+        // (|exponent| <= 40: scale^2, the unit of the scan's scores, must stay a float; rows smaller than 2^-27 simply lose
+        //  fp16 precision, which the measured residual reports)
+        const int e = std::max(-40, std::min(40, 13 - (int)std::floor(std::log2(bm[2]))));
+        f16_scale_ = std::ldexp(1.f, e);
+    }
+    float bm2[4] = {0.f, 0.f, 0.f, 0.f};
+    hip_check(launch_row_maxnorm(rows, (int)n, ld, dim, relative, d_bm.as<float>(), stream_, f16_scale_), "row residuals");
+    hip_check(hipMemcpyAsync(bm2, d_bm.ptr(), 16, hipMemcpyDeviceToHost, stream_), "bres16");
+    hip_check(hipStreamSynchronize(stream_), "row residuals");
+    bres16_ = bm2[3];
+    f16_scale_q_ = f16_scale_;
 }
 
 // restores the calling thread's current device on every way out of a scope that visits other devices
@@ -1146,7 +1184,7 @@ void Engine::knn_brute(const void* d_queries, size_t nq, size_t k, int32_t* d_id
             }
             ws_cand_.ensure(bf_cand_elems(f.fallback) * 8);
             ws_cnt_.ensure(bf_cnt_elems(f.fallback) * 4);
-            ws_f32_q_.ensure((size_t)f.qpad * f.dp * 2 * 2);
+            ws_f32_q_.ensure((size_t)f.qpad * f.dp * 2 * 3);   // bf16 hi, bf16 lo, fp16
             ws_u8_cand_.ensure(bf_f32_top8_elems(f) * 4);
             ws_u8_thr_.ensure(bf_f32_thr_bytes(f));
             ws_flags_.ensure((size_t)f.fallback.nqt * 4 + 64);
@@ -1156,6 +1194,7 @@ void Engine::knn_brute(const void* d_queries, size_t nq, size_t k, int32_t* d_id
             int* tile_fail = reinterpret_cast<int*>(thr + 2 * (size_t)f.qpad);
             char* qh = ws_f32_q_.as<char>();
             char* ql = qh + (size_t)f.qpad * f.dp * 2;
+            BfF16Side h16{d_f16_hi_.ptr(), d_auxp16_.as<float>(), ql + (size_t)f.qpad * f.dp * 2, f16_scale_, bres16_, f16_scale_q_};
             hipEvent_t eb = nullptr, ee = nullptr;
             if (prof_ && prof_events_.size() < 65536) {
                 hip_check(hipEventCreate(&eb), "hipEventCreate");
@@ -1170,7 +1209,7 @@ void Engine::knn_brute(const void* d_queries, size_t nq, size_t k, int32_t* d_id
                                          ws_u8_list_.as<uint32_t>(), ws_u8_listcnt_.as<int>(), tile_fail, ws_flags_.as<int>(),
                                          d_ids_.as<int32_t>(), d_ids, d_dists, d_cnt, eb, ee, stream,
                                          centred_ ? nullptr : static_cast<const float*>(d_queries), centred_ ? nullptr : ws_qpad_.as<float>(),
-                                         f.cosc ? ws_qaux_.as<float>() : nullptr, f.cosc ? ws_qsel_.as<float>() : nullptr, f.dp),
+                                         f.cosc ? ws_qaux_.as<float>() : nullptr, f.cosc ? ws_qsel_.as<float>() : nullptr, f.dp, h16),
                       "bf_f32_fast");
             last_path = 1;
             fast_flags_ = tile_fail;

@@ -242,8 +242,12 @@ class Engine {
     hipStream_t stream_ = nullptr;
     DevBuf d_rows_, d_rows_i8_, d_aux_, d_ids_, d_links0_, d_up_off_, d_up_links_, d_rownorm_;
     DevBuf d_auxh_;  // uint8 brute force: aux >> 1 (fast-path scan)
+    DevBuf d_f16_hi_, d_auxp16_;   // fp16 tiles of the selection rows times f16_scale_ and their start values (one-product scan)
     DevBuf d_bf_hi_, d_bf_lo_, d_auxp_, ws_f32_q_;  // f32 fast path: bf16 hi / lo tiles of the selection rows, padded aux, split queries
     bool have_bf16_ = false;
+    float f16_scale_q_ = 1.f;              // ... and of the batch's fp16 queries (the rows' scale, except centred cosine)
+    float f16_scale_ = 1.f, bres16_ = 0;   // one-product scan: power-of-two scale of its fp16 tiles, the rows' largest fp16 residual
+    void measure_rows_f16(const float* rows, size_t n, int ld, int dim, bool relative, float* bm);
     float bmax_ = 0;  // largest norm of the selection rows
     float bres_ = 0;  // their largest bf16 rounding residual (relative to the norm for the cosine spaces)
     DevBuf ws_u8_cand_, ws_u8_cnt_, ws_u8_thr_, ws_u8_list_, ws_u8_listcnt_;

@@ -1426,6 +1426,7 @@ __global__ __launch_bounds__(256) void bf_rerank_u8_list_kernel(RerankListArgs a
 // initial value, read from LDS straight into the MFMA registers.
 // ---------------------------------------------------------------------------------------
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 enum ScanMode : int { SC_L2 = 0, SC_DOT = 1, SC_COS = 2 };
 
@@ -1435,6 +1436,12 @@ struct BfScanF32Args {
     const float* auxp;        // [n_pad]: l2 -0.5|b|^2, cosine 1/|b|, dot 0; rows >= n: -inf (l2) / 0
     const __bf16* q_hi;       // [qpad][128]
     const __bf16* q_lo;
+    // one-product scan (round 3): fp16 tiles of the rows and queries times a power of two `scale` (3 more significant bits
+    // than bf16: an eighth of the rounding error, so the one-product bound E1 leaves room on far more data and the threshold
+    // sits closer to the k'-th score); scores, start values and thresholds of that scan are in units of scale_rows * scale_queries
+    const void* base_h16;     // [n_pad][dp] _Float16
+    const void* q_h16;        // [qpad][dp] _Float16
+    const float* auxp16;      // [n_pad] start values of the fp16 scan (l2: scale^2 * aux; cosine: aux)
     const float* thr;         // [qpad] pass <=> score >= thr
     uint32_t* list;           // [qpad][caph][nsplit][2] hit entries: block << 16 | row mask (see hit_mask_f32)
     int* list_cnt;            // [qpad][nsplit][2] rows listed
@@ -1850,7 +1857,7 @@ __global__ __launch_bounds__(NW * 64) void bf_scan_bf16_kernel(BfScanF32Args a) 
     auto issue_tile = [&](int stage) __attribute__((always_inline)) {
         const int slot = stage % kRing;
         const int row0 = r_begin + (stage / KCH) * stage_rows;
-        const unsigned long long sbase = (unsigned long long)(uintptr_t)a.base_hi + ((unsigned long long)row0 * kDp + (stage % KCH) * 128) * 2ull;
+        const unsigned long long sbase = (unsigned long long)(uintptr_t)a.base_h16 + ((unsigned long long)row0 * kDp + (stage % KCH) * 128) * 2ull;
         const uint32_t m0v = dma_lds0 + (uint32_t)slot * kStageBytes;
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Winline-asm"
@@ -1858,13 +1865,13 @@ __global__ __launch_bounds__(NW * 64) void bf_scan_bf16_kernel(BfScanF32Args a) 
         for (int jj = 0; jj < 16 / NW; ++jj)
             asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
                          :: "v"(dma_voff[jj]), "s"(sbase), "s"(m0v + (uint32_t)jj * 1024u) : "memory", "m0");
-        const unsigned long long abase = (unsigned long long)(uintptr_t)a.auxp + (unsigned long long)row0 * 4ull;
+        const unsigned long long abase = (unsigned long long)(uintptr_t)a.auxp16 + (unsigned long long)row0 * 4ull;
         asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1"
                      :: "v"(aux_voff), "s"(abase), "s"(aux_lds0 + (uint32_t)((stage % kAuxRing) * BF_BN * 4)) : "memory", "m0");
 #pragma clang diagnostic pop
     };
 
-    bf16x8 qh[QG][8 * KCH];
+    f16x8 qh[QG][8 * KCH];
     float thr[QG];
     int cnt[QG], ecnt[QG];
     uint32_t* lp[QG];
@@ -1874,7 +1881,7 @@ __global__ __launch_bounds__(NW * 64) void bf_scan_bf16_kernel(BfScanF32Args a) 
         const int qidx = (qt * NW + wave) * (32 * QG) + g * 32 + l31;
 #pragma unroll
         for (int kc = 0; kc < 8 * KCH; ++kc)
-            asm volatile("global_load_dwordx4 %0, %1, off" : "=a"(qh[g][kc]) : "v"(a.q_hi + (size_t)qidx * kDp + 16 * kc + 8 * h) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=a"(qh[g][kc]) : "v"(static_cast<const _Float16*>(a.q_h16) + (size_t)qidx * kDp + 16 * kc + 8 * h) : "memory");
         cnt[g] = 0;
         ecnt[g] = 0;
         if constexpr (SAMPLE) {
@@ -1975,7 +1982,7 @@ __global__ __launch_bounds__(NW * 64) void bf_scan_bf16_kernel(BfScanF32Args a) 
         }
     };
 
-    bf16x8 fh[4];
+    f16x8 fh[4];
     f32x16 iv;
 #pragma unroll
     for (int i = 0; i < 16; ++i) iv[i] = 0.f;
@@ -2051,17 +2058,17 @@ __global__ __launch_bounds__(NW * 64) void bf_scan_bf16_kernel(BfScanF32Args a) 
     // one MFMA of K-step kc.  A block's first MFMAs take the start values (-|b|^2 / 2, read from LDS into the pinned tuple
     // `iv`) as their C operand.  Through the builtin the compiler first COPIES the tuple into the accumulator's registers
     // (8 v_mov_b64 + an s_nop per block); the instruction written out names the pinned registers as C (round 3).
-    auto mfma_step = [&](f32x16& c, const bf16x8& q, int kc, bool first_ch) __attribute__((always_inline)) {
+    auto mfma_step = [&](f32x16& c, const f16x8& q, int kc, bool first_ch) __attribute__((always_inline)) {
         if constexpr (MODE == SC_L2) {
             if (kc == 0 && first_ch) {
                 if constexpr (NW == 4)
-                    asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(c) : "{v[224:227]}"(fh[0]), "a"(q), "{v[240:255]}"(iv));
+                    asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, %3" : "=&v"(c) : "{v[224:227]}"(fh[0]), "a"(q), "{v[240:255]}"(iv));
                 else
-                    asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(c) : "{v[96:99]}"(fh[0]), "a"(q), "{v[112:127]}"(iv));
+                    asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, %3" : "=&v"(c) : "{v[96:99]}"(fh[0]), "a"(q), "{v[112:127]}"(iv));
                 return;
             }
         }
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[kc % 4], q, (kc == 0 && first_ch) ? iv : c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[kc % 4], q, (kc == 0 && first_ch) ? iv : c, 0, 0, 0);
     };
     auto load_init = [&](uint32_t ax) __attribute__((always_inline)) {
         if constexpr (MODE == SC_L2) {
@@ -2235,17 +2242,21 @@ __global__ __launch_bounds__(NW * 64) void bf_scan_bf16_kernel(BfScanF32Args a) 
 
 // rows -> two bf16 tiles (hi = bf16(x), lo = bf16(x - hi)), padded to 128 columns and n_pad rows; auxp = aux with the
 // pad rows' value
+// h16 (nullable) = fp16(scale * x) for the one-product scan, auxp16 its start values (aux * aux16_mul)
 __global__ void split_bf16_kernel(const float* src, int rows, int rows_pad, int ld, int dim, __bf16* hi, __bf16* lo,
-                                  const float* aux, float aux_pad, float* auxp, int dp) {
+                                  const float* aux, float aux_pad, float* auxp, int dp, _Float16* h16, float scale,
+                                  float* auxp16, float aux16_mul) {
     const size_t total = (size_t)rows_pad * dp;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const size_t r = i / (size_t)dp;
         const int c = (int)(i - r * dp);
         const float v = (r < (size_t)rows && c < dim) ? src[r * ld + c] : 0.f;
         const __bf16 hh = (__bf16)v;
-        hi[i] = hh;
+        if (hi) hi[i] = hh;
         if (lo) lo[i] = (__bf16)(v - (float)hh);
+        if (h16) h16[i] = (_Float16)(scale * v);
         if (c == 0 && auxp) auxp[r] = r < (size_t)rows ? (aux ? aux[r] : 0.f) : aux_pad;
+        if (c == 0 && auxp16) auxp16[r] = r < (size_t)rows ? (aux ? aux[r] * aux16_mul : 0.f) : aux_pad;
     }
 }
 
@@ -2256,7 +2267,7 @@ __global__ void split_bf16_kernel(const float* src, int rows, int rows_pad, int 
 //   adaptive path's flags, both shared-threshold regions of the fallback selections.
 __global__ void bf_f32_prep_kernel(const float* raw, int nq, int dim, const float* sel, int qpad, int ld, float* pad_out,
                                    __bf16* hi, __bf16* lo, int* clr0, int n0, int* clr1, int n1, uint32_t* clr2, size_t n2,
-                                   int dp) {
+                                   int dp, _Float16* h16, float scale) {
     const size_t gtid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, gsz = (size_t)gridDim.x * blockDim.x;
     const size_t total = (size_t)qpad * dp;
     for (size_t i = gtid; i < total; i += gsz) {
@@ -2270,8 +2281,9 @@ __global__ void bf_f32_prep_kernel(const float* raw, int nq, int dim, const floa
             v = c < dim ? sel[r * ld + c] : 0.f;
         }
         const __bf16 hh = (__bf16)v;
-        hi[i] = hh;
+        if (hi) hi[i] = hh;
         if (lo) lo[i] = (__bf16)(v - (float)hh);
+        h16[i] = (_Float16)(scale * v);
     }
     for (size_t i = gtid; i < (size_t)n0; i += gsz) clr0[i] = 0;
     for (size_t i = gtid; i < (size_t)n1; i += gsz) clr1[i] = 0;
@@ -2282,14 +2294,20 @@ __global__ void bf_f32_prep_kernel(const float* raw, int nq, int dim, const floa
 // in every lane):  |q.b - q^.b^| <= |q - q^||b| + |q^||b - b^|  with the ACTUAL rounding residual of this query and the
 // largest residual of the rows (bres; relative to |b| for the cosine score, where bscale = 1), plus the f32 accumulation
 // of the MFMAs.  Typically ~0.4 of the worst case 2^-7 |q||b|.
-__device__ __forceinline__ float one_product_error(const float* qs, int dim, int lane, float bscale, float bres) {
+// Round 3: the scan's operands are fp16(scale * x); everything here is in the scan's units (queries and rows times `scale`:
+// bscale = scale * |b|max -- or scale for the cosine score --, bres the rows' largest residual |scale b - fp16(scale b)|).
+// A query beyond fp16's range (|scale q_i| > 65504 -> inf) gets an infinite bound: its tile leaves the one-product scan.
+__device__ __forceinline__ float one_product_error(const float* qs, int dim, int lane, float bscale, float bres, float scale) {
     float ss = 0.f, rr = 0.f;
+    bool over = false;
     for (int d = lane; d < dim; d += 64) {
-        const float v = qs[d], w = v - (float)(__bf16)v;
+        const float v = scale * qs[d], w = v - (float)(_Float16)v;
+        over |= !(fabsf(v) <= 65504.f);
         ss = fmaf(v, v, ss);
         rr = fmaf(w, w, rr);
     }
     const float qn = sqrtf(wave_sum(ss)), qr = sqrtf(wave_sum(rr));
+    if (__any(over)) return INFINITY;
     return 1.01f * (qr * bscale + 1.004f * qn * bres) + 2e-5f * qn * bscale;
 }
 
@@ -2313,7 +2331,7 @@ template <int NPER>
 __global__ __launch_bounds__(256) void bf_f32_threshold_kernel(const float* top8, int nlists, int depth, int r, int rcap, int nq,
                                                                int qpad, const float* queries_sel, int ldb, int dim, float bscale,
                                                                float bres, int group_q, int force_precise, float* thr3,
-                                                               float* thr1, int* precise) {
+                                                               float* thr1, int* precise, float scale_q, float unit) {
     const int lane = threadIdx.x & 63, q = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (q >= qpad) return;
     if (q >= nq) {  // padding queries: nothing passes
@@ -2331,7 +2349,7 @@ __global__ __launch_bounds__(256) void bf_f32_threshold_kernel(const float* top8
         const int l = depth == 4 ? idx >> 2 : idx >> 3, j = idx - l * depth;   // (depth is 4 or 8)
         key[i] = idx < total ? f32_ord(top8[((size_t)q * nlists + l) * 8 + j]) : 0u;
     }
-    const float e1 = one_product_error(queries_sel + (size_t)q * ldb, dim, lane, bscale, bres);
+    const float e1 = one_product_error(queries_sel + (size_t)q * ldb, dim, lane, bscale, bres, scale_q);   // (the scan's units)
     const uint32_t T = total >= r ? wave_rth_largest_u32<NPER>(key, r) : 0u;
     const float t3 = total >= r ? ord_f32(T) : -INFINITY;   // s^_r
     float t1 = t3;
@@ -2364,7 +2382,7 @@ __global__ __launch_bounds__(256) void bf_f32_threshold_kernel(const float* top8
         }
     }
     if (lane == 0) {
-        thr3[q] = t3 - 1.02f * e1;
+        thr3[q] = (t3 - 1.02f * e1) / unit;   // (the split-product scan runs on the unscaled bf16 tiles)
         thr1[q] = force_precise == 2 ? INFINITY : t1;   // (2: NMSLIB_GPU_DEBUG & 8192 -- a scan without hits, timing experiments)
         if (!ok) atomicOr(&precise[q / group_q], 1);
     }
@@ -2391,6 +2409,7 @@ struct RerankListF32Args {
     int no_split;              // rows longer than 128: no split-product scan -- a `precise` tile goes to the adaptive kernel
     float bmax;                // largest row norm of the selection rows
     float bres;                // largest bf16 rounding residual of the selection rows (see row_maxnorm_kernel)
+    float scale, scale_q, bres16;   // one-product tiles: the fp16 scan's scales of rows / queries, the rows' largest fp16 residual (scaled)
     int sel_dim, sel_ld;       // columns / row stride of queries_sel (dim / ldb, or the augmented queries' when qaux is set)
     const float* qaux;         // centred cosine / angular: [qpad][4] = |q'|^2, |q| - |mu|, |q|, flag (0: zero-norm query); else null
     unsigned long long* prof;  // NMSLIB_GPU_DEBUG & 4096: phase clocks (100 MHz), summed over the workgroups
@@ -2447,7 +2466,7 @@ __global__ __launch_bounds__(256) void bf_rerank_f32_list_kernel(RerankListF32Ar
         float ss = 0.f;
         for (int d = lane; d < a.sel_dim; d += 64) ss = fmaf(qs[d], qs[d], ss);
         ss = wave_sum(ss);
-        const float e1 = split_product ? 0.f : one_product_error(qs, a.sel_dim, lane, a.space == SP_L2 || a.space == SP_NEGDOT || a.qaux ? a.bmax : 1.0f, a.bres);
+        const float e1 = split_product ? 0.f : one_product_error(qs, a.sel_dim, lane, a.scale * (a.space == SP_L2 || a.space == SP_NEGDOT || a.qaux ? a.bmax : 1.0f), a.bres16, a.scale_q);
         if (lane == 0) {
             s_qn2 = ss;
             s_e1 = e1;
@@ -2688,7 +2707,12 @@ __global__ __launch_bounds__(256) void bf_rerank_f32_list_kernel(RerankListF32Ar
                 e = 6.1036e-5f * qn;
             }
             const float t = s_thr;
-            if (!split_product) e = s_e1;   // one bf16 product
+            if (!split_product) {   // one fp16 product: threshold, bound and score in the scan's units (scale^2)
+                const float unit = a.scale * a.scale_q;
+                sk *= unit;
+                extra *= unit;
+                e = s_e1;
+            }
             e += extra + 1e-6f * (fabsf(sk) + fabsf(t));  // rounding of sk itself
             if (!(sk - t >= e)) atomicOr(&a.tile_fail[q / a.fail_queries], 1);
         }
@@ -2712,27 +2736,37 @@ __global__ __launch_bounds__(256) void bf_rerank_f32_list_kernel(RerankListF32Ar
 
 // largest row norm -> out[0]; largest bf16 rounding residual |b - bf16(b)| -> out[1] (relative to |b| if `relative`: the
 // cosine score divides by it); atomicMax on the bits of non-negative floats
-__global__ void row_maxnorm_kernel(const float* rows, int n, int ld, int dim, int relative, unsigned* out_bits) {
+// out[2] = largest |element| (the fp16 scale is chosen from it); out[3] = largest fp16 residual |scale b - fp16(scale b)| of
+// the rows times `scale16` (0: not wanted) -- relative to |b| (i.e. scale16 * the relative residual) if `relative`
+__global__ void row_maxnorm_kernel(const float* rows, int n, int ld, int dim, int relative, unsigned* out_bits, float scale16) {
     const int lane = threadIdx.x & 63;
     const int wpb = blockDim.x >> 6;
-    float mb = 0.f, mr = 0.f;   // this wave's maxima over its rows: one pair of atomics per wave
+    float mb = 0.f, mr = 0.f, ma = 0.f, mh = 0.f;   // this wave's maxima over its rows: one set of atomics per wave
     for (int row = blockIdx.x * wpb + (threadIdx.x >> 6); row < n; row += gridDim.x * wpb) {
         const float* p = rows + (size_t)row * ld;
-        float s = 0.f, r = 0.f;
+        float s = 0.f, r = 0.f, rh = 0.f;
         for (int d = lane; d < dim; d += 64) {
             const float v = p[d], w = v - (float)(__bf16)v;
+            const float vs = scale16 * v, wh = vs - (float)(_Float16)vs;
             s = fmaf(v, v, s);
             r = fmaf(w, w, r);
+            rh = fmaf(wh, wh, rh);
+            ma = fmaxf(ma, fabsf(v));
         }
         s = wave_sum(s);
         r = wave_sum(r);
-        const float nb = sqrtf(s), nr = sqrtf(r);
+        rh = wave_sum(rh);
+        const float nb = sqrtf(s), nr = sqrtf(r), nh = sqrtf(rh);
         mb = fmaxf(mb, nb);
         mr = fmaxf(mr, relative ? (nb > 0.f ? nr / nb : 0.f) : nr);
+        mh = fmaxf(mh, relative ? (nb > 0.f ? nh / nb : 0.f) : nh);
     }
+    ma = wave_max(ma);
     if (lane == 0) {
         atomicMax(out_bits, __float_as_uint(mb));
         atomicMax(out_bits + 1, __float_as_uint(mr));
+        atomicMax(out_bits + 2, __float_as_uint(ma));
+        atomicMax(out_bits + 3, __float_as_uint(mh));
     }
 }
 
@@ -3765,24 +3799,27 @@ BfF32Fast bf_f32_fast_plan(int n, int dim, int nq, int k, int space, bool cosine
     return f;
 }
 
-hipError_t launch_row_maxnorm(const float* rows, int n, int ld, int dim, bool relative_residual, float* out, hipStream_t s) {
-    hipError_t e = hipMemsetAsync(out, 0, 8, s);
+hipError_t launch_row_maxnorm(const float* rows, int n, int ld, int dim, bool relative_residual, float* out, hipStream_t s,
+                              float scale16) {
+    hipError_t e = hipMemsetAsync(out, 0, 16, s);
     if (e != hipSuccess || n == 0) return e;
     int grid = (n + 3) / 4;
     if (grid > 4096) grid = 4096;
     hipLaunchKernelGGL(row_maxnorm_kernel, dim3(grid), dim3(256), 0, s, rows, n, ld, dim, relative_residual ? 1 : 0,
-                       reinterpret_cast<unsigned*>(out));
+                       reinterpret_cast<unsigned*>(out), scale16);
     return hipGetLastError();
 }
 
 hipError_t launch_split_bf16(const float* src, int rows, int rows_pad, int ld, int dim, void* hi, void* lo,
-                             const float* aux, float aux_pad, float* auxp, hipStream_t s, int dp) {
+                             const float* aux, float aux_pad, float* auxp, hipStream_t s, int dp, void* h16, float scale,
+                             float* auxp16, float aux16_mul) {
     const size_t total = (size_t)rows_pad * dp;
     if (total == 0) return hipSuccess;
     size_t grid = (total + 255) / 256;
     if (grid > 16384) grid = 16384;
     hipLaunchKernelGGL(split_bf16_kernel, dim3((unsigned)grid), dim3(256), 0, s, src, rows, rows_pad, ld, dim,
-                       static_cast<__bf16*>(hi), static_cast<__bf16*>(lo), aux, aux_pad, auxp, dp);
+                       static_cast<__bf16*>(hi), static_cast<__bf16*>(lo), aux, aux_pad, auxp, dp, static_cast<_Float16*>(h16),
+                       scale, auxp16, aux16_mul);
     return hipGetLastError();
 }
 
@@ -3846,7 +3883,7 @@ hipError_t launch_bf_f32_fast(const BfF32Fast& f, int space, int n, int dim, int
                               uint32_t* list, int* list_cnt, int* tile_fail, int* flags_fb, const int32_t* ext_ids,
                               int32_t* out_ids, float* out_dists, int32_t* out_cnt, hipEvent_t scan_begin,
                               hipEvent_t scan_end, hipStream_t s, const float* queries_raw, float* queries_pad_out,
-                              const float* qaux_cosc, const float* queries_centred, int sel_ld) {
+                              const float* qaux_cosc, const float* queries_centred, int sel_ld, const BfF16Side& h16) {
     // centred cosine / angular (f.cosc): queries_sel holds the augmented queries q+ [qpad][sel_ld] of f.sel_dim columns and
     // base_hi / base_lo the augmented rows (bmax / bres: theirs); queries_centred + qaux_cosc serve the adaptive fallback
     const int sdim = f.cosc ? f.sel_dim : dim, sld = f.cosc ? sel_ld : ldb;
@@ -3861,8 +3898,9 @@ hipError_t launch_bf_f32_fast(const BfF32Fast& f, int space, int n, int dim, int
         size_t grid = (work + 255) / 256;
         if (grid > 2048) grid = 2048;
         hipLaunchKernelGGL(bf_f32_prep_kernel, dim3((unsigned)grid), dim3(256), 0, s, queries_raw, nq, sdim, queries_sel, f.qpad,
-                           sld, queries_pad_out, static_cast<__bf16*>(q_hi), f.kch > 1 ? nullptr : static_cast<__bf16*>(q_lo),
-                           tile_fail, 2 * f.nqt, flags_fb, fb.nqt, gthr, gwords, f.dp);
+                           sld, queries_pad_out, f.kch > 1 ? nullptr : static_cast<__bf16*>(q_hi),
+                           f.kch > 1 ? nullptr : static_cast<__bf16*>(q_lo),
+                           tile_fail, 2 * f.nqt, flags_fb, fb.nqt, gthr, gwords, f.dp, static_cast<_Float16*>(h16.q_h16), h16.scale_q);
         e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
@@ -3878,6 +3916,9 @@ hipError_t launch_bf_f32_fast(const BfF32Fast& f, int space, int n, int dim, int
     a.auxp = auxp;
     a.q_hi = static_cast<const __bf16*>(q_hi);
     a.q_lo = static_cast<const __bf16*>(q_lo);
+    a.base_h16 = h16.base_h16;
+    a.q_h16 = h16.q_h16;
+    a.auxp16 = h16.auxp16;
     a.n = n;
     a.nqt = f.nqt;
     // 1. sample pass (one product: the scores carry the error E1) + thresholds + the choice of the scan per query tile
@@ -3895,8 +3936,8 @@ hipError_t launch_bf_f32_fast(const BfF32Fast& f, int space, int n, int dim, int
         const int depth = f.rcap <= 64 && f.s_nsplit >= 32 ? 4 : 8;
         const dim3 tgrid((f.qpad + 3) / 4);
 #define BF_THR_ARGS                                                                                                               \
-    top8, 2 * f.s_nsplit, depth, f.r, f.rcap, nq, f.qpad, queries_sel, sld, sdim, f.mode == 2 ? 1.0f : bmax, bres, f.tq,          \
-        f.force_precise ? 1 : (dbg_nohit ? 2 : 0), thr, thr1, precise
+    top8, 2 * f.s_nsplit, depth, f.r, f.rcap, nq, f.qpad, queries_sel, sld, sdim, h16.scale * (f.mode == 2 ? 1.0f : bmax), h16.bres16, f.tq, \
+        f.force_precise ? 1 : (dbg_nohit ? 2 : 0), thr, thr1, precise, h16.scale_q, h16.scale * h16.scale_q
         if (2 * f.s_nsplit * depth <= 512) hipLaunchKernelGGL(bf_f32_threshold_kernel<8>, tgrid, dim3(256), 0, s, BF_THR_ARGS);
         else hipLaunchKernelGGL(bf_f32_threshold_kernel<16>, tgrid, dim3(256), 0, s, BF_THR_ARGS);   // (s_nsplit <= 64)
 #undef BF_THR_ARGS
@@ -3949,6 +3990,9 @@ hipError_t launch_bf_f32_fast(const BfF32Fast& f, int space, int n, int dim, int
     r.queries_sel = queries_sel;
     r.sel_dim = sdim;
     r.sel_ld = sld;
+    r.scale = h16.scale;
+    r.scale_q = h16.scale_q;
+    r.bres16 = h16.bres16;
     r.qaux = f.cosc ? qaux_cosc : nullptr;
     r.thr = thr;
     r.thr1 = thr1;

@@ -147,9 +147,25 @@ inline size_t bf_f32_top8_elems(const BfF32Fast& f) { return (size_t)f.qpad * f.
 inline int bf_f32_rows_padded(int n) { return (n + BF_BN - 1) / BF_BN * BF_BN + BF_BN; }
 // rows (or queries) -> bf16 hi / lo tiles [rows_pad][128]; auxp [rows_pad] = aux, aux_pad behind `rows` (optional)
 // largest row norm -> *out (device float)
-hipError_t launch_row_maxnorm(const float* rows, int n, int ld, int dim, bool relative_residual, float* out, hipStream_t s);
+// out (16 bytes): [0] largest norm, [1] largest bf16 residual, [2] largest |element|, [3] largest fp16 residual of scale16 * row
+hipError_t launch_row_maxnorm(const float* rows, int n, int ld, int dim, bool relative_residual, float* out, hipStream_t s,
+                              float scale16 = 0.f);
+// hi / lo / auxp: bf16 tiles of the split-product scan (nullable); h16 / auxp16: fp16(scale * row) tiles and start values
+// (aux * aux16_mul) of the one-product scan (nullable)
 hipError_t launch_split_bf16(const float* src, int rows, int rows_pad, int ld, int dim, void* hi, void* lo,
-                             const float* aux, float aux_pad, float* auxp, hipStream_t s, int dp = 128);
+                             const float* aux, float aux_pad, float* auxp, hipStream_t s, int dp = 128, void* h16 = nullptr,
+                             float scale = 1.f, float* auxp16 = nullptr, float aux16_mul = 1.f);
+// the one-product scan's side of a float fast-path batch: fp16 tiles of the rows (built at finalize), their start values,
+// the power-of-two scale, the rows' largest fp16 residual (scaled units), and the workspace of the batch's fp16 queries
+struct BfF16Side {
+    const void* base_h16;
+    const float* auxp16;
+    void* q_h16;
+    float scale;       // rows
+    float bres16;
+    float scale_q;     // queries (l2: the rows' scale -- the start values carry the product; centred cosine: rows are divided by
+                       // their norm, queries are not)
+};
 hipError_t launch_bf_f32_fast(const BfF32Fast& f, int space, int n, int dim, int ldb, int nq, int k, const float* base_orig,
                               const float* sel_rows, const float* aux, const void* base_hi, const void* base_lo,
                               const float* auxp, float bmax, float bres, const float* queries_orig, const float* queries_sel,
@@ -157,7 +173,8 @@ hipError_t launch_bf_f32_fast(const BfF32Fast& f, int space, int n, int dim, int
                               uint32_t* list, int* list_cnt, int* tile_fail, int* flags_fb, const int32_t* ext_ids, int32_t* out_ids,
                               float* out_dists, int32_t* out_cnt, hipEvent_t scan_begin, hipEvent_t scan_end,
                               hipStream_t s, const float* queries_raw = nullptr, float* queries_pad_out = nullptr,
-                              const float* qaux_cosc = nullptr, const float* queries_centred = nullptr, int sel_ld = 0);
+                              const float* qaux_cosc = nullptr, const float* queries_centred = nullptr, int sel_ld = 0,
+                              const BfF16Side& h16 = BfF16Side{});
 // centred cosine / angular on the fast path: augmented rows / queries (see row_aug_cosc_kernel)
 hipError_t launch_row_aug_cosc(const float* orig, const float* centred, int n, int ldb, int dim, double mu_norm, float lambda,
                                float* out, int ldo, int* zero_rows, hipStream_t s);
