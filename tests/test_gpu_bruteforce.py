@@ -749,3 +749,42 @@ def test_centred_cosine_fast_path(space, kind, monkeypatch):
     np.testing.assert_array_equal(ids1, ids2)
     np.testing.assert_array_equal(ds1.view(np.uint32), ds2.view(np.uint32))
     idx.close()
+
+
+@pytest.mark.parametrize("space", ["l2", "negdotprod", "cosinesimil"])
+@pytest.mark.parametrize("kind", ["tiny", "huge", "outlier_row", "outlier_query", "wide_range"])
+def test_f32_fast_path_value_ranges(space, kind, monkeypatch):
+    """The one-product scan runs on fp16(scale * x) (round 3): the scale comes from the rows' largest |element|, the error
+    bound from MEASURED residuals, and a query beyond fp16's range gets an infinite bound.  Whatever the magnitudes -- rows
+    of 1e-12 or 1e12, one huge element among small ones, a query a million times larger than the rows, columns spread over
+    twelve decades -- the answers are the adaptive f32 path's bit for bit (both end in the reference formula)."""
+    n, D, nq, k = 70000, 48, 300, 10
+    X, Q = refio.s_lowrank(n, D, 501), refio.s_lowrank(nq, D, 502)
+    if kind == "tiny":
+        X, Q = X * np.float32(1e-12), Q * np.float32(1e-12)
+    elif kind == "huge":
+        X, Q = X * np.float32(1e12), Q * np.float32(1e12)
+    elif kind == "outlier_row":
+        X = X.copy()
+        X[12345, 7] = np.float32(3e6)
+    elif kind == "outlier_query":
+        Q = Q.copy()
+        Q[5] *= np.float32(1e6)
+    else:
+        w = np.float32(10.0) ** np.linspace(-6, 6, D).astype(np.float32)
+        X, Q = X * w, Q * w
+    idx = make_index(space, "seq_search", X)
+    ids, ds, cnt = idx.knnQueryBatch(Q, k)
+    st = idx.stats()
+    print(kind, space, st)
+    assert st["last_path"] == 1, st
+    monkeypatch.setenv("NMSLIB_GPU_F32_FAST", "0")
+    ids0, ds0, _ = idx.knnQueryBatch(Q, k)
+    assert idx.stats()["last_path"] == 0
+    monkeypatch.delenv("NMSLIB_GPU_F32_FAST")
+    np.testing.assert_array_equal(ids, ids0)
+    np.testing.assert_array_equal(ds.view(np.uint32), ds0.view(np.uint32))
+    sel = np.r_[0:10, nq - 6:nq]
+    opos, odist, _ = orc.seq_search(space, X, Q[sel], k + 22)
+    assert refio.recall_nmslib(ids[sel], opos, odist, k) >= 0.999
+    idx.close()
