@@ -1442,6 +1442,7 @@ struct BfScanF32Args {
     const void* base_h16;     // [n_pad][dp] _Float16
     const void* q_h16;        // [qpad][dp] _Float16
     const float* auxp16;      // [n_pad] start values of the fp16 scan (l2: scale^2 * aux; cosine: aux)
+    int prio_half;            // one-product scan, eight waves: waves 4..7 run at priority 1
     const float* thr;         // [qpad] pass <=> score >= thr
     uint32_t* list;           // [qpad][caph][nsplit][2] hit entries: block << 16 | row mask (see hit_mask_f32)
     int* list_cnt;            // [qpad][nsplit][2] rows listed
@@ -2096,6 +2097,9 @@ __global__ __launch_bounds__(NW * 64) void bf_scan_bf16_kernel(BfScanF32Args a) 
     //  the branch between the copies is merged with COPIES of registers whose reads are in flight -- tests/test_isa_audit.py.)
     auto main_loop = [&](auto stag_tag) __attribute__((always_inline)) {
     constexpr int kStag = decltype(stag_tag)::value;
+    // (static priority for the second-dispatched half, the arbitration loser of every SIMD pair: same guide, item 4;
+    //  NMSLIB_GPU_BF16_PRIO=0 in the launcher's environment switches it off for experiments)
+    if (kStag != 0 && a.prio_half) __builtin_amdgcn_s_setprio(1);
     load_init(aux_a);
 #pragma unroll
     for (int kc = 0; kc < kPre; ++kc) load_frag(Off0{}, kc);
@@ -2515,11 +2519,14 @@ __global__ __launch_bounds__(256) void bf_rerank_f32_list_kernel(RerankListF32Ar
             ok[c] = d < a.dim;
             qv[c] = ok[c] ? qq[d] : 0.f;
         }
-        for (int j0 = wave * 16; j0 < total; j0 += 64) {
-            uint32_t pos[4];
-            float xv[4][8];
+        // (four passes of 4 rows per wave requested together: 64 rows of the query in flight per workgroup round; eight
+        //  passes -- two round trips instead of three at ~150 listed rows -- measured no faster: 35 vs 31 us for this phase)
+        constexpr int kU = 4;
+        for (int j0 = wave * (4 * kU); j0 < total; j0 += 16 * kU) {
+            uint32_t pos[kU];
+            float xv[kU][8];
     #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < kU; ++u) {
                 const int j = j0 + 4 * u + rg;
                 pos[u] = (uint32_t)keys[j < total ? j : total - 1];
                 const float* row = a.base + (size_t)pos[u] * a.ldb + sub;
@@ -2528,7 +2535,7 @@ __global__ __launch_bounds__(256) void bf_rerank_f32_list_kernel(RerankListF32Ar
             }
             __builtin_amdgcn_wave_barrier();
     #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < kU; ++u) {
                 float p0[4], p1[4], p2[4];   // per virtual lane: the fma chain over dimensions v, v + 64
     #pragma unroll
                 for (int v = 0; v < 4; ++v) {
@@ -3917,6 +3924,10 @@ hipError_t launch_bf_f32_fast(const BfF32Fast& f, int space, int n, int dim, int
     a.q_hi = static_cast<const __bf16*>(q_hi);
     a.q_lo = static_cast<const __bf16*>(q_lo);
     a.base_h16 = h16.base_h16;
+    {
+        static const int prio = getenv("NMSLIB_GPU_BF16_PRIO") ? atoi(getenv("NMSLIB_GPU_BF16_PRIO")) : 0;
+        a.prio_half = prio;
+    }
     a.q_h16 = h16.q_h16;
     a.auxp16 = h16.auxp16;
     a.n = n;
