@@ -375,8 +375,8 @@ def run_workload(a, name, cx):
         roof = {"bound": "mfma", "achieved": round(ops / kern_s / 1e12, 2), "peak": PEAK_I8_MFMA_TOPS, "unit": "TOP/s",
                 "kernel": "bf_scan_u8_kernel" if last_path == 3 else "bf_select_u8_kernel"}
     elif last_path == 1:
-        # selection on the bf16 matrix cores.  Per query tile the threshold kernel picks the scan: ONE bf16 product per
-        # element (bf_scan_bf16_kernel) where the sample shows room for its error, else the split product (f32 operands
+        # selection on the fp16 / bf16 matrix cores.  Per query tile the threshold kernel picks the scan: ONE fp16 product per
+        # element (bf_scan_bf16_kernel; operands fp16(s x), s a power of two) where the sample shows room for its error, else the split product (f32 operands
         # as hi + lo bf16: qh.bh + qh.bl + ql.bh, bf_scan_f32_kernel).  `achieved` counts the algorithmic 2*Q*N*D.
         flops = 2.0 * nq * rows_local * dim             # 
         tiles, precise = int(stats.get("fast_tiles", 0)), int(stats.get("fast_tiles_precise", 0))
