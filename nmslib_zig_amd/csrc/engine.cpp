@@ -1277,9 +1277,9 @@ void Engine::knn_hnsw(const void* d_queries, size_t nq, size_t k, int32_t* d_ids
         knn_hnsw_old(d_queries, nq, k, d_ids, d_dists, d_cnt, stream);
         return;
     }
-    if (std::max<size_t>(ef, k) > 1024 || dg_.maxM0 > 126 || dg_.maxM > 62) {
-        // beyond the LDS kernels' sorted array, or adjacency lists longer than two words per lane (M / maxM > 62,
-        // maxM0 > 126): the same algorithm with the array in HBM and lists walked in chunks (slices of bounded workspace)
+    if (std::max<size_t>(ef, k) > 1024 || hnsw_nbcap(dg_) > HNSW_NBCAP_LDS) {
+        // beyond the LDS kernels' sorted array, or adjacency lists longer than their frontier arrays (maxM0 > 254): the
+        // same algorithm with the array in HBM and lists walked in chunks (slices of bounded workspace)
         int32_t* cnt2 = d_cnt;
         if (!cnt2) {
             ws_outcnt_.ensure(nq * 4);

@@ -5,12 +5,6 @@
 
 namespace gfxknn {
 
-// entries of the frontier arrays: a multiple of 64 that holds the longest adjacency list (level 0 or above)
-inline int hnsw_nbcap(const HnswDeviceGraph& g) {
-    const int longest = g.maxM0 > g.maxM ? g.maxM0 : g.maxM;
-    return longest <= 62 ? 64 : (longest + 64) / 64 * 64;
-}
-
 struct HnswArgs {
     HnswDeviceGraph g;
     const void* queries;

@@ -32,6 +32,61 @@ constexpr int SA_EMAX_MAX = 16;  // sorted array up to 64*16 = 1024 items
 // EMAX = sorted-array items per lane (cap <= 64*EMAX): 2 for ef <= 128, 4 for <= 256, 16 otherwise.
 // WIDE: level-0 lists of more than 62 neighbours (maxM0 up to 126, i.e. M >= 32): second adjacency chunk,
 // 128-entry neighbour staging, two insertion rounds.  Kept out of the common instantiation.
+// ---- adjacency lists of any length (round 3: M / maxM > 62, maxM0 > 126 -- hnsw.cc:189-208 takes any M) -------------
+// The kernels above give a list one or two words per lane.  SearchOld and the HBM-array SearchV1Merge walk longer lists in
+// chunks of 64 neighbours (list order kept: neighbour i is list word i + 1); their frontier arrays hold a.nbcap entries.
+// unvisited neighbours of list[] -> nbr[0 .. m), returns m
+template <class Visit>
+__device__ __forceinline__ int collect_unvisited_any(const int* list, int* nbr, int lane, Visit&& visit) {
+    const int cnt = __builtin_amdgcn_readfirstlane(list[0]);
+    int m = 0;
+    for (int c0 = 0; c0 < cnt; c0 += 64) {
+        const int i = c0 + lane;
+        const int nb = i < cnt ? list[i + 1] : 0;
+        bool isn = false;
+        if (i < cnt) isn = visit((uint32_t)nb);
+        const u64 mask = __ballot(isn);
+        if (isn) nbr[m + __popcll(mask & ((1ull << lane) - 1ull))] = nb;
+        m += __popcll(mask);
+    }
+    return m;
+}
+// one greedy step on an upper level over a list of any length: the FIRST neighbour attaining the minimum, if it is closer
+// than curdist (the sequential "if (d < curdist)" scan of hnsw.cc / hnsw_distfunc_opt.cc:176-196).  Returns the list length.
+template <int SPACE>
+__device__ __forceinline__ int greedy_step_any(const HnswDeviceGraph& g, const int* list, const float* qv, const uint8_t* qb,
+                                               int qnorm, int* nbr, float* nd, int lane, int& cur, float& curdist,
+                                               bool& changed) {
+    const int cnt = __builtin_amdgcn_readfirstlane(list[0]);
+    for (int c0 = 0; c0 < cnt; c0 += 64)
+        if (c0 + lane < cnt) nbr[c0 + lane] = list[c0 + lane + 1];
+    __builtin_amdgcn_wave_barrier();
+    if (cnt > 0) {
+        frontier_distances<SPACE>(g, qv, qb, qnorm, nbr, nd, cnt, lane);
+        u64 key = ~0ull;
+        for (int c0 = 0; c0 < cnt; c0 += 64) {
+            const int i = c0 + lane;
+            if (i < cnt) {
+                const u64 k2 = ((u64)f32_ord(nd[i]) << 32) | (uint32_t)i;
+                key = k2 < key ? k2 : key;
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const u64 other = __shfl_xor(key, o, 64);
+            key = other < key ? other : key;
+        }
+        const float dmin = ord_f32((uint32_t)(key >> 32));
+        if (dmin < curdist) {
+            curdist = dmin;
+            cur = nbr[(uint32_t)key];
+            changed = true;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    return cnt;
+}
+
 template <int SPACE, bool BITSET, int SA_EMAX, bool WIDE>
 __device__ __forceinline__ void hnsw_search_body(const HnswArgs& a, char* smem, const int q, uint32_t* const bits) {
     const HnswDeviceGraph& g = a.g;
@@ -43,7 +98,7 @@ __device__ __forceinline__ void hnsw_search_body(const HnswArgs& a, char* smem, 
     int* idu = reinterpret_cast<int*>(keys + a.capa);              // [capa]  id | used<<31
     const int qfloats = kU8 ? 32 : g.ldv;
     float* qv = reinterpret_cast<float*>(idu + a.capa);            // [ldv] (u8: 128 bytes)
-    constexpr int nbcap = WIDE ? 128 : 64;                         // neighbours of one expansion (maxM0 <= 126)
+    const int nbcap = WIDE ? a.nbcap : 64;                         // neighbours of one expansion (wide lists: a multiple of 64 >= maxM0, maxM)
     int* nbr = reinterpret_cast<int*>(qv + qfloats);               // [nbcap]
     float* nd = reinterpret_cast<float*>(nbr + nbcap);             // [nbcap]
     float* sk = nd + nbcap;                                        // [64] accepted keys, sorted
@@ -132,6 +187,11 @@ __device__ __forceinline__ void hnsw_search_body(const HnswArgs& a, char* smem, 
         while (changed) {
             changed = false;
             const int64_t off = g.up_off[cur] + (int64_t)(lvl - 1) * (g.maxM + 1);
+            if (WIDE && g.maxM > 62) {   // upper-level lists longer than one word per lane
+                hops_up++;
+                ndc += greedy_step_any<SPACE>(g, g.up_links + off, qv, qb, qnorm, nbr, nd, lane, cur, curdist, changed);
+                continue;
+            }
             const int v = (lane <= g.maxM) ? g.up_links[off + lane] : 0;
             const int cntl = __builtin_amdgcn_readfirstlane(v);
             const int nb = __shfl(v, lane + 1, 64);
@@ -244,15 +304,18 @@ __device__ __forceinline__ void hnsw_search_body(const HnswArgs& a, char* smem, 
             const u64 nmask = __ballot(isn);
             m = __popcll(nmask);
             if (isn) nbr[__popcll(nmask & ((1ull << lane) - 1ull))] = nb;
-            if (WIDE && cntn > 63) {
-                // wide level-0 lists (maxM0 > 62, i.e. M >= 32): neighbours 63.. are list words 64.., read on demand
-                int nb2 = 0;
-                if (64 + lane <= g.maxM0) nb2 = g.links0[(size_t)c * (g.maxM0 + 1) + 64 + lane];
-                bool isn2 = false;
-                if (63 + lane < cntn) isn2 = visit((uint32_t)nb2);
-                const u64 nmask2 = __ballot(isn2);
-                if (isn2) nbr[m + __popcll(nmask2 & ((1ull << lane) - 1ull))] = nb2;
-                m += __popcll(nmask2);
+            if (WIDE) {
+                // wide level-0 lists (maxM0 > 62, i.e. M >= 32): neighbours 63.. are list words 64.., read on demand in chunks
+                // of 64 (round 3: any number of chunks the frontier arrays hold -- a.nbcap)
+                for (int c0 = 63; c0 < cntn; c0 += 64) {
+                    int nb2 = 0;
+                    if (c0 + 1 + lane <= g.maxM0) nb2 = g.links0[(size_t)c * (g.maxM0 + 1) + c0 + 1 + lane];
+                    bool isn2 = false;
+                    if (c0 + lane < cntn) isn2 = visit((uint32_t)nb2);
+                    const u64 nmask2 = __ballot(isn2);
+                    if (isn2) nbr[m + __popcll(nmask2 & ((1ull << lane) - 1ull))] = nb2;
+                    m += __popcll(nmask2);
+                }
             }
             nvisited += m;
             if (!BITSET && nvisited > (a.table_size - (a.table_size >> 3))) {
@@ -614,61 +677,6 @@ __device__ __forceinline__ void wave_sync() {
 __device__ __forceinline__ u64 pack_kid(float key, int id) { return ((u64)__float_as_uint(key) << 32) | (uint32_t)id; }
 __device__ __forceinline__ float kid_key(u64 v) { return __uint_as_float((uint32_t)(v >> 32)); }
 __device__ __forceinline__ int kid_id(u64 v) { return (int)(uint32_t)v; }
-
-// ---- adjacency lists of any length (round 3: M / maxM > 62, maxM0 > 126 -- hnsw.cc:189-208 takes any M) -------------
-// The kernels above give a list one or two words per lane.  SearchOld and the HBM-array SearchV1Merge walk longer lists in
-// chunks of 64 neighbours (list order kept: neighbour i is list word i + 1); their frontier arrays hold a.nbcap entries.
-// unvisited neighbours of list[] -> nbr[0 .. m), returns m
-template <class Visit>
-__device__ __forceinline__ int collect_unvisited_any(const int* list, int* nbr, int lane, Visit&& visit) {
-    const int cnt = __builtin_amdgcn_readfirstlane(list[0]);
-    int m = 0;
-    for (int c0 = 0; c0 < cnt; c0 += 64) {
-        const int i = c0 + lane;
-        const int nb = i < cnt ? list[i + 1] : 0;
-        bool isn = false;
-        if (i < cnt) isn = visit((uint32_t)nb);
-        const u64 mask = __ballot(isn);
-        if (isn) nbr[m + __popcll(mask & ((1ull << lane) - 1ull))] = nb;
-        m += __popcll(mask);
-    }
-    return m;
-}
-// one greedy step on an upper level over a list of any length: the FIRST neighbour attaining the minimum, if it is closer
-// than curdist (the sequential "if (d < curdist)" scan of hnsw.cc / hnsw_distfunc_opt.cc:176-196).  Returns the list length.
-template <int SPACE>
-__device__ __forceinline__ int greedy_step_any(const HnswDeviceGraph& g, const int* list, const float* qv, const uint8_t* qb,
-                                               int qnorm, int* nbr, float* nd, int lane, int& cur, float& curdist,
-                                               bool& changed) {
-    const int cnt = __builtin_amdgcn_readfirstlane(list[0]);
-    for (int c0 = 0; c0 < cnt; c0 += 64)
-        if (c0 + lane < cnt) nbr[c0 + lane] = list[c0 + lane + 1];
-    __builtin_amdgcn_wave_barrier();
-    if (cnt > 0) {
-        frontier_distances<SPACE>(g, qv, qb, qnorm, nbr, nd, cnt, lane);
-        u64 key = ~0ull;
-        for (int c0 = 0; c0 < cnt; c0 += 64) {
-            const int i = c0 + lane;
-            if (i < cnt) {
-                const u64 k2 = ((u64)f32_ord(nd[i]) << 32) | (uint32_t)i;
-                key = k2 < key ? k2 : key;
-            }
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const u64 other = __shfl_xor(key, o, 64);
-            key = other < key ? other : key;
-        }
-        const float dmin = ord_f32((uint32_t)(key >> 32));
-        if (dmin < curdist) {
-            curdist = dmin;
-            cur = nbr[(uint32_t)key];
-            changed = true;
-        }
-    }
-    __builtin_amdgcn_wave_barrier();
-    return cnt;
-}
 
 template <int SPACE, bool BITSET, bool WIDE>
 __global__ __launch_bounds__(64) void hnsw_search_old_kernel(HnswArgs a, OldWs w) {
@@ -1317,7 +1325,7 @@ HnswSearchPlan hnsw_make_plan(const HnswDeviceGraph& g, int nq, int k, int ef, b
     p.ef = ef;
     p.cap = ef > k ? ef : k;
     const bool u8 = g.space == SP_L2SQR_SIFT;
-    const size_t fixed = (size_t)((p.cap + 3) & ~3) * 8 + (u8 ? 128 : (size_t)g.ldv * 4) + (size_t)(2 * (g.maxM0 > 62 ? 128 : 64) + 2 * 64) * 4;
+    const size_t fixed = (size_t)((p.cap + 3) & ~3) * 8 + (u8 ? 128 : (size_t)g.ldv * 4) + (size_t)(2 * hnsw_nbcap(g) + 2 * 64) * 4;
     // expected visited nodes ~ (maxM0 * expansions); expansions ~ ef.  Size the table for 2x that
     // and never let LDS push residency below 4 waves per CU (160 KB / 4).
     int want = 1 << ilog2((g.maxM0 > 0 ? g.maxM0 : 32) * p.cap * 2);
@@ -1375,7 +1383,7 @@ static hipError_t launch_space_w(const HnswArgs& a, const HnswSearchPlan& p, hip
 
 template <int SPACE, int EMAX>
 static hipError_t launch_space_e(const HnswArgs& a, const HnswSearchPlan& p, hipStream_t s) {
-    if (a.g.maxM0 > 62) return launch_space_w<SPACE, EMAX, true>(a, p, s);
+    if (a.g.maxM0 > 62 || a.g.maxM > 62) return launch_space_w<SPACE, EMAX, true>(a, p, s);
     return launch_space_w<SPACE, EMAX, false>(a, p, s);
 }
 
@@ -1397,9 +1405,10 @@ hipError_t launch_hnsw_search_ex(const HnswDeviceGraph& g, const HnswSearchPlan&
                               int32_t* out_ndc, int32_t* out_hops, int32_t* out_hops_up,
                               int32_t* status, hipStream_t s) {
     if (p.nq == 0) return hipSuccess;
-    if (p.cap > 64 * SA_EMAX_MAX || g.maxM0 > 126 || g.maxM > 62) return hipErrorInvalidValue;
+    if (p.cap > 64 * SA_EMAX_MAX || hnsw_nbcap(g) > HNSW_NBCAP_LDS) return hipErrorInvalidValue;
     HnswArgs a{};
     a.g = g;
+    a.nbcap = hnsw_nbcap(g);
     a.queries = queries;
     a.query_rows = query_rows;
     a.start_nodes = start_nodes;

@@ -237,6 +237,16 @@ struct HnswSearchPlan {
     int heap_lds, heap_cap;    // heap entries in LDS / in total per query (the rest lives in the HBM workspace)
     int a_in_lds, r_in_lds;    // closest-queue values (ef floats) / result queue (k pairs) in LDS?
 };
+// entries of the frontier arrays: a multiple of 64 that holds the longest adjacency list (level 0 or above)
+inline int hnsw_nbcap(const HnswDeviceGraph& g) {
+    const int longest = g.maxM0 > g.maxM ? g.maxM0 : g.maxM;
+    return longest <= 62 ? 64 : (longest + 64) / 64 * 64;
+}
+
+// the LDS search kernels hold frontiers of up to this many neighbours (lists up to maxM0 = 254, i.e. M <= 127); longer lists
+// go to the HBM-array kernel
+constexpr int HNSW_NBCAP_LDS = 256;
+
 HnswSearchPlan hnsw_make_plan(const HnswDeviceGraph& g, int nq, int k, int ef, bool force_bitset);
 // Plan of the SearchOld kernel (hnsw_distfunc_opt.cc:46-150): no limit on ef or k.  heap_cap = 0 picks the default
 // bound on the candidate heap (queries that outgrow it report status 2 and are retried with heap_cap = n).

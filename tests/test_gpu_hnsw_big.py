@@ -48,11 +48,13 @@ def test_v1merge_big_with_ties_is_exact():
     idx.close()
 
 
-@pytest.mark.parametrize("space,M,maxM,maxM0", [("l2", 64, None, None), ("cosinesimil", 70, None, None), ("l2", 20, 90, 200)])
+@pytest.mark.parametrize("space,M,maxM,maxM0", [("l2", 64, None, None), ("cosinesimil", 70, None, None), ("l2", 20, 90, 200),
+                                                 ("l2", 20, 70, 300)])
 def test_any_M_same_graph_same_walk(space, M, maxM, maxM0, tmp_path):
     """M / maxM > 62 or maxM0 > 126 (hnsw.cc:189-208 takes any M): built on the host in the reference's order, searched by
-    the kernels that walk adjacency lists in chunks of 64 (collect_unvisited_any).  Same graph as the oracle's build, and on
-    it the same ids, distances and work counters for SearchV1Merge and SearchOld."""
+    the kernels that walk adjacency lists in chunks of 64: the LDS SearchV1Merge kernel up to maxM0 = 254 (frontier arrays of
+    256 entries), the HBM-array one beyond (the last case), SearchOld always.  Same graph as the oracle's build, and on it the
+    same ids, distances and work counters for SearchV1Merge and SearchOld."""
     from tests.test_gpu_hnsw_build import graph_of
     n, D, nq, k = 4000, 24, 96, 10
     X, Q = refio.s_lowrank(n, D, 811), refio.s_lowrank(nq, D, 812)
